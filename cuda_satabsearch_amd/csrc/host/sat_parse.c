@@ -1,0 +1,202 @@
+/*
+ * sat_parse.c - ASCII tableau + SSE-distance-matrix reader.  See sat_parse.h.
+ *
+ * Cell semantics kept from the reference reader (they are what existing
+ * databases rely on, quirks included):
+ *   - a tableau cell j of a row sits at text columns 3j, 3j+1
+ *     (parsetableaux.c:216-217); the diagonal cell is an SSE type: 'e?' -> 0,
+ *     otherwise by second letter a/i/g -> 1/2/3 (parsetableaux.c:52-76);
+ *     off-diagonal: first letter P R O L ? -> high nibble 0..4, second letter
+ *     E D S T ? -> low nibble 0..4 (parsetableaux.c:88-140); anything else is
+ *     fatal (exit status 1);
+ *   - a distance cell j is strtof() at text column 7j (parsetableaux.c:288), so
+ *     a value >= 100 A (printed 7 wide by the db builder) shifts the rest of
+ *     that row: reproduced as is;
+ *   - the record header is read with fscanf("%8s %d\n") (parsetableaux.c:391),
+ *     which also swallows the blank separator line and any leading blanks of
+ *     the first tableau row;
+ *   - order > 111 is skipped with a warning (parsetableaux.c:457-465).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "sat_parse.h"
+
+void sat_set_init(sat_struct_set *set)
+{
+    memset(set, 0, sizeof(*set));
+}
+
+void sat_set_free(sat_struct_set *set)
+{
+    free(set->order);
+    free(set->name);
+    free(set->cell_off);
+    free(set->tab);
+    free(set->dist);
+    memset(set, 0, sizeof(*set));
+}
+
+static int grow_entries(sat_struct_set *set)
+{
+    if (set->count < set->capacity)
+        return 0;
+    int ncap = set->capacity ? set->capacity * 2 : 1024;
+    int *o = (int *)realloc(set->order, (size_t)ncap * sizeof(int));
+    if (!o) return -1;
+    set->order = o;
+    char *nm = (char *)realloc(set->name, (size_t)ncap * (SAT_LABELSIZE + 1));
+    if (!nm) return -1;
+    set->name = nm;
+    int64_t *co = (int64_t *)realloc(set->cell_off, (size_t)ncap * sizeof(int64_t));
+    if (!co) return -1;
+    set->cell_off = co;
+    set->capacity = ncap;
+    return 0;
+}
+
+static int grow_cells(sat_struct_set *set, int64_t extra)
+{
+    if (set->cells + extra <= set->cells_cap)
+        return 0;
+    int64_t ncap = set->cells_cap ? set->cells_cap * 2 : (1 << 16);
+    while (ncap < set->cells + extra)
+        ncap *= 2;
+    uint8_t *t = (uint8_t *)realloc(set->tab, (size_t)ncap);
+    if (!t) return -1;
+    set->tab = t;
+    float *d = (float *)realloc(set->dist, (size_t)ncap * sizeof(float));
+    if (!d) return -1;
+    set->dist = d;
+    set->cells_cap = ncap;
+    return 0;
+}
+
+int sat_set_append(sat_struct_set *set, const char *name, int order,
+                   const uint8_t *tab_tri, const float *dist_tri)
+{
+    int64_t ncell = order > 0 ? (int64_t)order * (order + 1) / 2 : 0;
+    if (grow_entries(set) || grow_cells(set, ncell))
+        return -1;
+    int s = set->count++;
+    set->order[s] = order;
+    char *dst = set->name + (size_t)s * (SAT_LABELSIZE + 1);
+    memset(dst, 0, SAT_LABELSIZE + 1);
+    strncpy(dst, name, SAT_LABELSIZE);
+    set->cell_off[s] = set->cells;
+    if (ncell) {
+        memcpy(set->tab + set->cells, tab_tri, (size_t)ncell);
+        memcpy(set->dist + set->cells, dist_tri, (size_t)ncell * sizeof(float));
+    }
+    set->cells += ncell;
+    return s;
+}
+
+static uint8_t ssetype_code(const char *c)
+{
+    if (c[0] == 'e')
+        return SAT_SSE_E;
+    switch (c[1]) {
+    case 'a': return SAT_SSE_XA;
+    case 'i': return SAT_SSE_XI;
+    case 'g': return SAT_SSE_XG;
+    default:
+        fprintf(stderr, "Bad helix type %c\n", c[1]);
+        exit(1);
+    }
+}
+
+static uint8_t nibble_of(char c, const char *alphabet)
+{
+    const char *p = c ? strchr(alphabet, c) : NULL;
+    if (!p) {
+        fprintf(stderr, "invalid tableaux code %c\n", c);
+        exit(1);
+    }
+    return (uint8_t)(p - alphabet);
+}
+
+static uint8_t tableau_code(const char *c)
+{
+    /* position in the alphabet string is the nibble value; '?' is 4 */
+    uint8_t hi = nibble_of(c[0], "PROL?");
+    uint8_t lo = nibble_of(c[1], "EDST?");
+    return (uint8_t)((hi << 4) | lo);
+}
+
+static void read_line(FILE *fp, char *buf)
+{
+    memset(buf, 0, SAT_MAX_LINE_LEN);
+    if (!fgets(buf, SAT_MAX_LINE_LEN, fp))
+        buf[0] = '\0';
+}
+
+int sat_read_structures(FILE *fp, sat_struct_set *set, const char *what)
+{
+    static char buf[SAT_MAX_LINE_LEN];
+    uint8_t *tri_tab = (uint8_t *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2);
+    float *tri_dist = (float *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2 * sizeof(float));
+    char name[SAT_LABELSIZE + 1];
+    int order, added = 0, skipped = 0;
+
+    if (!tri_tab || !tri_dist) {
+        free(tri_tab);
+        free(tri_dist);
+        return -1;
+    }
+    while (!feof(fp)) {
+        if (fscanf(fp, "%8s %d\n", name, &order) != 2)
+            break; /* end of input */
+        if (order > SAT_MAXDIM) {
+            fprintf(stderr, "Tableau %s order %d is too large (max is %d)\n",
+                    name, order, SAT_MAXDIM);
+            fprintf(stderr, "WARNING: excluded %s structure %s as it is too large\n",
+                    what, name);
+            for (int i = 0; i < 2 * order; i++)
+                read_line(fp, buf);
+            skipped++;
+            continue;
+        }
+        int64_t c = 0;
+        for (int i = 0; i < order; i++) {
+            read_line(fp, buf);
+            for (int j = 0; j <= i; j++, c++)
+                tri_tab[c] = (i == j) ? ssetype_code(&buf[3 * j])
+                                      : tableau_code(&buf[3 * j]);
+        }
+        c = 0;
+        for (int i = 0; i < order; i++) {
+            read_line(fp, buf);
+            for (int j = 0; j <= i; j++, c++)
+                tri_dist[c] = strtof(&buf[7 * j], NULL);
+        }
+        if (sat_set_append(set, name, order, tri_tab, tri_dist) < 0) {
+            free(tri_tab);
+            free(tri_dist);
+            return -1;
+        }
+        added++;
+    }
+    if (skipped > 0)
+        fprintf(stderr, "WARNING: skipped %d %s tableaux of order > %d\n",
+                skipped, what, SAT_MAXDIM);
+    set->skipped += skipped;
+    free(tri_tab);
+    free(tri_dist);
+    return added;
+}
+
+void sat_set_expand(const sat_struct_set *set, int s, int pitch,
+                    uint8_t *tab_dense, float *dist_dense)
+{
+    int n = set->order[s];
+    const uint8_t *t = set->tab + set->cell_off[s];
+    const float *d = set->dist + set->cell_off[s];
+    int64_t c = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++, c++) {
+            tab_dense[(size_t)i * pitch + j] = t[c];
+            tab_dense[(size_t)j * pitch + i] = t[c];
+            dist_dense[(size_t)i * pitch + j] = d[c];
+            dist_dense[(size_t)j * pitch + i] = d[c];
+        }
+}

@@ -1,0 +1,78 @@
+/*
+ * sat_parse.h - ASCII tableau + SSE-distance-matrix reader (host side, plain C).
+ *
+ * Same input grammar and the same fixed-column cell semantics as the reference
+ * reader (nvcc_src_current/parsetableaux.c:193-227 parse_tableau, :276-294
+ * parse_distmatrix, :317-506 read_database, :522-632 read_queries), but a
+ * different in-memory model: the reference keeps every structure in a dense
+ * padded 96x96 or 111x111 slot (46 KB / 61 KB per entry); here every structure
+ * is stored once as its packed lower triangle (1 B code + 4 B distance per
+ * cell, diagonal included), which is also the layout uploaded to HBM.
+ *
+ * Lower-triangle cell (i,j), j <= i, of structure s lives at
+ *     set->cell_off[s] + i*(i+1)/2 + j
+ * in set->tab (code bytes) and set->dist (floats).
+ */
+#ifndef SAT_PARSE_H
+#define SAT_PARSE_H
+
+#include <stdio.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAT_MAXDIM       111   /* saparams.h:15  largest structure accepted          */
+#define SAT_MAXDIM_SMALL  96   /* saparams.h:17  "small" class limit (MAXDIM_GPU)      */
+#define SAT_LABELSIZE      8   /* saparams.h:24                                        */
+#define SAT_MAX_LINE_LEN 2048  /* parsetableaux.h                                      */
+
+/* encodings, parsetableaux.c:13-33 */
+#define SAT_SSE_E  0
+#define SAT_SSE_XA 1
+#define SAT_SSE_XI 2
+#define SAT_SSE_XG 3
+
+typedef struct sat_struct_set {
+    int       count;      /* structures held                                          */
+    int       capacity;
+    int64_t   cells;      /* total lower-triangle cells held                          */
+    int64_t   cells_cap;
+    int      *order;      /* [count]  number of SSEs                                  */
+    char     *name;       /* [count][SAT_LABELSIZE+1], NUL terminated                 */
+    int64_t  *cell_off;   /* [count]  first cell of structure s                       */
+    uint8_t  *tab;        /* [cells]  packed code bytes (diagonal = SSE type)         */
+    float    *dist;       /* [cells]  distances in Angstrom (diagonal = type as x.000)*/
+    int       skipped;    /* structures dropped because order > SAT_MAXDIM            */
+} sat_struct_set;
+
+void sat_set_init(sat_struct_set *set);
+void sat_set_free(sat_struct_set *set);
+
+/* Append one structure given as packed lower triangles; returns its index or -1. */
+int sat_set_append(sat_struct_set *set, const char *name, int order,
+                   const uint8_t *tab_tri, const float *dist_tri);
+
+/*
+ * Read every "name order / tableau rows / distance rows" record up to EOF.
+ * `what` is "database" or "query" (only used in the warnings, which are worded
+ * as parsetableaux.c:459, 500, 603, 627).  Returns the number of structures
+ * appended, or -1 on allocation failure.  Unknown code letters terminate the
+ * process with exit(1), as the reference does (parsetableaux.c:70-73,109-112).
+ */
+int sat_read_structures(FILE *fp, sat_struct_set *set, const char *what);
+
+/* Expand structure s to dense symmetric pitch x pitch arrays (row-major). */
+void sat_set_expand(const sat_struct_set *set, int s, int pitch,
+                    uint8_t *tab_dense, float *dist_dense);
+
+static inline const char *sat_set_name(const sat_struct_set *set, int s)
+{
+    return set->name + (size_t)s * (SAT_LABELSIZE + 1);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAT_PARSE_H */
