@@ -1,0 +1,90 @@
+"""Build the native pieces of cuda_satabsearch_amd in-tree.
+
+    python -m cuda_satabsearch_amd.build [--oracle] [--ref]
+
+* libsatabsearch.so   HIP kernels + C ABI (include/satabsearch.h), hipcc --offload-arch=gfx950
+* libsathost.so       host-only C: ASCII reader + Gumbel statistics (csrc/host/)
+* bin/satabsearch     the command line (csrc/host/sat_main.c), links both
+
+`--oracle` additionally runs oracle/Makefile (test infrastructure, never linked into
+the product), `--ref` also its `ref` target when /root/reference is mounted.
+hipcc cross-compiles gfx950 code objects without a GPU present.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(CSRC, "host")
+INC = os.path.join(ROOT, "include")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+CC = os.environ.get("CC") or "gcc"
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_host(force=False):
+    out = os.path.join(PKG, "libsathost.so")
+    srcs = [os.path.join(HOST, f) for f in ("sat_parse.c", "sat_gumbel.c")]
+    deps = srcs + [os.path.join(HOST, f) for f in ("sat_parse.h", "sat_gumbel.h")]
+    if force or _stale(out, deps):
+        _run([CC, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", HOST, "-o", out] + srcs + ["-lm"])
+    return out
+
+
+def build_device(force=False):
+    out = os.path.join(PKG, "libsatabsearch.so")
+    srcs = [os.path.join(CSRC, "sat_capi.hip")]
+    deps = srcs + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(INC, "satabsearch.h")]
+    if force or _stale(out, deps):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+              "-I", INC, "-I", CSRC, "-o", out] + srcs)
+    return out
+
+
+def build_cli(force=False):
+    src = os.path.join(HOST, "sat_main.c")
+    if not os.path.exists(src):
+        return None
+    bindir = os.path.join(PKG, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    out = os.path.join(bindir, "satabsearch")
+    deps = [src, os.path.join(PKG, "libsatabsearch.so"), os.path.join(PKG, "libsathost.so")]
+    if force or _stale(out, deps):
+        _run([CC, "-O2", "-Wall", "-Wextra", "-I", INC, "-I", HOST, "-o", out, src,
+              "-L", PKG, "-lsatabsearch", "-lsathost", "-lm", "-Wl,-rpath,$ORIGIN/.."])
+    return out
+
+
+def build_oracle(ref=False):
+    odir = os.path.join(ROOT, "oracle")
+    _run(["make", "-s", "-C", odir, "all"])
+    if ref and os.path.isdir("/root/reference/nvcc_src_current"):
+        _run(["make", "-s", "-C", odir, "ref"])
+
+
+def build_all(force=False, oracle=False, ref=False):
+    build_host(force)
+    build_device(force)
+    build_cli(force)
+    if oracle:
+        build_oracle(ref)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, oracle="--oracle" in sys.argv or "--ref" in sys.argv,
+              ref="--ref" in sys.argv)

@@ -1,0 +1,504 @@
+// sat_capi.hip - C ABI (include/satabsearch.h) over the gfx950 SA kernel.
+//
+// Host side of the drop-in boundary: device memory, the packed database store, the
+// query buffer, the Metropolis table, size-class dispatch and launches.  Replaces
+// the device glue of nvcc_src_current/cudaSaTabsearch.cu (init_rng :258-264,
+// copyQueryToConstantMemory :486-558, alloc/upload :896-984, launch/sync/download
+// :1036-1087 and :1128-1270).  No CPU search path exists in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "satabsearch.h"
+#include "sat_sa_kernel.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t err__ = (expr);                                                      \
+        if (err__ != hipSuccess)                                                        \
+            return fail(err__ == hipErrorOutOfMemory ? SAT_ENOMEM : SAT_EDEVICE,        \
+                        "%s failed: %s", #expr, hipGetErrorString(err__));              \
+    } while (0)
+
+// db entries are launched in classes of similar order so that every launch sizes its
+// LDS for the largest member of the class only
+constexpr int kNumBuckets = 7;
+const int kBucketMax[kNumBuckets] = { 16, 32, 48, 64, 80, 96, 111 };
+constexpr size_t kLdsLimit = 160 * 1024;
+
+template <typename T> void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace
+
+struct sat_ctx {
+    int device = 0;
+    uint64_t seed = SAT_DEFAULT_SEED;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // database shard
+    int n_entries = 0;
+    int32_t *d_orders = nullptr;
+    int64_t *d_cell_off = nullptr;
+    uint8_t *d_tab = nullptr;
+    float *d_dist = nullptr;
+    uint32_t *d_ordinal = nullptr;
+    int32_t *d_lists = nullptr;             // entry indices grouped by bucket
+    int bucket_begin[kNumBuckets + 1] = { 0 };
+    int bucket_n2max[kNumBuckets] = { 0 };
+    std::vector<int32_t> h_orders;
+
+    // query
+    int n1 = 0, n1p = 0;
+    uint32_t query_ordinal = 0;
+    uint2 *d_qcells = nullptr;
+    uint8_t *d_qtypes = nullptr;
+
+    // Metropolis table
+    float *d_ptab = nullptr;
+    int32_t *d_prow = nullptr;
+
+    // results
+    int32_t *d_scores = nullptr;
+    int8_t *d_ssemaps = nullptr;
+    size_t ssemaps_cap = 0;
+};
+
+namespace {
+
+int build_metropolis_table(sat_ctx *ctx)
+{
+    // P[iter][nd] = expf((float)(-nd) / temp_iter), temp_0 = 10, temp *= 0.95f per step
+    // (saparams.h:34-37, K.cu:1030, 1166, 1189), computed with the host libm.  A draw
+    // u is never below 2^-32 (rocrand_uniform.h:65-68), so entries <= 2^-32 can never
+    // accept and each row is cut after its last entry above that bound.
+    const int max_nd = 4 * (SAT_MAXDIM - 1);     // |delta| <= 4 per other query SSE
+    const float umin = 2.3283064e-10f;
+    std::vector<float> tab;
+    std::vector<int32_t> rows(2 * SAT_MAXITER);
+    volatile float temp = 10.0f;
+    for (int it = 0; it < SAT_MAXITER; it++) {
+        int last = 0;
+        std::vector<float> row(max_nd + 1);
+        for (int nd = 0; nd <= max_nd; nd++) {
+            volatile float x = (float)(-nd) / temp;
+            row[nd] = expf(x);
+            if (row[nd] > umin) last = nd;
+        }
+        rows[2 * it] = (int32_t)tab.size();
+        rows[2 * it + 1] = last;
+        tab.insert(tab.end(), row.begin(), row.begin() + last + 1);
+        temp = temp * 0.95f;
+    }
+    HIP_TRY(hipMalloc(&ctx->d_ptab, tab.size() * sizeof(float)));
+    HIP_TRY(hipMalloc(&ctx->d_prow, rows.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(ctx->d_ptab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_prow, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return SAT_OK;
+}
+
+void free_db(sat_ctx *ctx)
+{
+    dev_free(ctx->d_orders);
+    dev_free(ctx->d_cell_off);
+    dev_free(ctx->d_tab);
+    dev_free(ctx->d_dist);
+    dev_free(ctx->d_ordinal);
+    dev_free(ctx->d_lists);
+    dev_free(ctx->d_scores);
+    dev_free(ctx->d_ssemaps);
+    ctx->ssemaps_cap = 0;
+    ctx->n_entries = 0;
+    ctx->h_orders.clear();
+}
+
+typedef void (*kernel_fn)(const SatKernelArgs);
+
+template <int N1P> kernel_fn pick_m2w(int m2w, bool qlds)
+{
+    if (qlds) {
+        if (m2w == 1) return sat_sa_kernel<N1P, 1, true>;
+        if (m2w == 2) return sat_sa_kernel<N1P, 2, true>;
+        return sat_sa_kernel<N1P, 4, true>;
+    }
+    if constexpr (N1P >= 64) {
+        if (m2w == 1) return sat_sa_kernel<N1P, 1, false>;
+        if (m2w == 2) return sat_sa_kernel<N1P, 2, false>;
+        return sat_sa_kernel<N1P, 4, false>;
+    }
+    return nullptr;
+}
+
+kernel_fn pick_kernel(int n1p, int m2w, bool qlds)
+{
+    switch (n1p) {
+    case 16: return pick_m2w<16>(m2w, qlds);
+    case 32: return pick_m2w<32>(m2w, qlds);
+    case 64: return pick_m2w<64>(m2w, qlds);
+    default: return pick_m2w<112>(m2w, qlds);
+    }
+}
+
+int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t stream)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (ctx->n_entries <= 0) return fail(SAT_ESTATE, "no database uploaded");
+    if (ctx->n1 <= 0) return fail(SAT_ESTATE, "no query set");
+    if (maxstart < 1) return fail(SAT_EINVAL, "maxstart must be >= 1 (got %d)", maxstart);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    if (lsoln) {
+        size_t need = (size_t)ctx->n_entries * ctx->n1;
+        if (need > ctx->ssemaps_cap) {
+            dev_free(ctx->d_ssemaps);
+            HIP_TRY(hipMalloc(&ctx->d_ssemaps, need));
+            ctx->ssemaps_cap = need;
+        }
+    }
+
+    SatKernelArgs a;
+    a.orders = ctx->d_orders;
+    a.cell_off = ctx->d_cell_off;
+    a.tab_tri = ctx->d_tab;
+    a.dist_tri = ctx->d_dist;
+    a.ordinal = ctx->d_ordinal;
+    a.qcells = ctx->d_qcells;
+    a.qtypes = ctx->d_qtypes;
+    a.n1 = ctx->n1;
+    a.lorder = lorder ? 1 : 0;
+    a.lsoln = lsoln ? 1 : 0;
+    a.maxstart = maxstart;
+    a.seed_q = ctx->seed + ((uint64_t)ctx->query_ordinal << 32);
+    a.ptab = ctx->d_ptab;
+    a.prow = ctx->d_prow;
+    a.scores = ctx->d_scores;
+    a.ssemaps = ctx->d_ssemaps;
+
+    for (int b = 0; b < kNumBuckets; b++) {
+        const int count = ctx->bucket_begin[b + 1] - ctx->bucket_begin[b];
+        if (count == 0) continue;
+        const int n2max = ctx->bucket_n2max[b];
+        const int m2w = n2max <= 32 ? 1 : (n2max <= 64 ? 2 : 4);
+
+        // threads: one lane per restart up to 256; shrink until the workgroup fits the LDS
+        int threads = (maxstart + 63) / 64 * 64;
+        if (threads > 256) threads = 256;
+        bool qlds = true;
+        size_t lds = 0;
+        for (;;) {
+            lds = satk::lds_bytes(ctx->n1, ctx->n1p, n2max, threads, lsoln != 0, qlds);
+            if (lds <= kLdsLimit) break;
+            if (threads > 64) { threads -= 64; continue; }
+            if (qlds && ctx->n1p >= 64) {              // query cells stay in L1/L2 instead
+                qlds = false;
+                threads = (maxstart + 63) / 64 * 64;
+                if (threads > 256) threads = 256;
+                continue;
+            }
+            return fail(SAT_EINVAL, "workgroup does not fit in LDS (n1=%d n2=%d)", ctx->n1, n2max);
+        }
+        kernel_fn fn = pick_kernel(ctx->n1p, m2w, qlds);
+        if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", ctx->n1p, m2w);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        a.entry_list = ctx->d_lists + ctx->bucket_begin[b];
+        hipLaunchKernelGGL(fn, dim3(count), dim3(threads), lds, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return SAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sat_last_error(void) { return g_err; }
+
+int sat_abi_version(void) { return SAT_ABI_VERSION; }
+
+int sat_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+sat_ctx *sat_ctx_create(int device, uint64_t seed)
+{
+    int n = sat_device_count();
+    if (n <= 0) {
+        fail(SAT_ENODEVICE, "no HIP device available (this library has no CPU path)");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        fail(SAT_ENODEVICE, "device %d out of range (0..%d)", device, n - 1);
+        return nullptr;
+    }
+    sat_ctx *ctx = new (std::nothrow) sat_ctx();
+    if (!ctx) {
+        fail(SAT_ENOMEM, "out of host memory");
+        return nullptr;
+    }
+    ctx->device = device;
+    ctx->seed = seed;
+    auto init = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&ctx->ev0));
+        HIP_TRY(hipEventCreate(&ctx->ev1));
+        return build_metropolis_table(ctx);
+    };
+    if (init() != SAT_OK) {
+        sat_ctx_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+void sat_ctx_destroy(sat_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_db(ctx);
+    dev_free(ctx->d_qcells);
+    dev_free(ctx->d_qtypes);
+    dev_free(ctx->d_ptab);
+    dev_free(ctx->d_prow);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                         const int64_t *cell_off, const uint8_t *tab_tri,
+                         const float *dist_tri, const int64_t *db_ordinal)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (n_entries <= 0 || !orders || !cell_off || !tab_tri || !dist_tri)
+        return fail(SAT_EINVAL, "empty database or null array");
+    int64_t cells_end = 0;
+    for (int e = 0; e < n_entries; e++) {
+        const int n = orders[e];
+        if (n < 1 || n > SAT_MAXDIM)
+            return fail(SAT_EINVAL, "entry %d: order %d outside 1..%d", e, n, SAT_MAXDIM);
+        if (cell_off[e] < 0) return fail(SAT_EINVAL, "entry %d: negative cell offset", e);
+        for (int i = 0; i < n; i++) {
+            uint8_t t = tab_tri[cell_off[e] + (int64_t)i * (i + 1) / 2 + i];
+            if (t > 3) return fail(SAT_EINVAL, "entry %d: SSE %d has type code %u (0..3 expected)", e, i, t);
+        }
+        int64_t end = cell_off[e] + (int64_t)n * (n + 1) / 2;
+        if (end > cells_end) cells_end = end;
+        if (db_ordinal && (db_ordinal[e] < 0 || db_ordinal[e] > 0xFFFFFFFFll))
+            return fail(SAT_EINVAL, "entry %d: db ordinal out of range", e);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_db(ctx);
+
+    // bucket lists, file order kept inside a bucket
+    std::vector<int32_t> lists;
+    lists.reserve(n_entries);
+    for (int b = 0; b < kNumBuckets; b++) {
+        ctx->bucket_begin[b] = (int)lists.size();
+        ctx->bucket_n2max[b] = 0;
+        const int lo = b == 0 ? 0 : kBucketMax[b - 1];
+        for (int e = 0; e < n_entries; e++)
+            if (orders[e] > lo && orders[e] <= kBucketMax[b]) {
+                lists.push_back(e);
+                if (orders[e] > ctx->bucket_n2max[b]) ctx->bucket_n2max[b] = orders[e];
+            }
+    }
+    ctx->bucket_begin[kNumBuckets] = (int)lists.size();
+
+    std::vector<uint32_t> ord(n_entries);
+    for (int e = 0; e < n_entries; e++) ord[e] = db_ordinal ? (uint32_t)db_ordinal[e] : (uint32_t)e;
+
+    HIP_TRY(hipMalloc(&ctx->d_orders, (size_t)n_entries * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_cell_off, (size_t)n_entries * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&ctx->d_ordinal, (size_t)n_entries * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_lists, (size_t)n_entries * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_tab, (size_t)cells_end));
+    HIP_TRY(hipMalloc(&ctx->d_dist, (size_t)cells_end * sizeof(float)));
+    HIP_TRY(hipMalloc(&ctx->d_scores, (size_t)n_entries * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(ctx->d_orders, orders, (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_cell_off, cell_off, (size_t)n_entries * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_ordinal, ord.data(), (size_t)n_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_lists, lists.data(), (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tab, tab_tri, (size_t)cells_end, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_dist, dist_tri, (size_t)cells_end * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(ctx->d_scores, 0, (size_t)n_entries * sizeof(int32_t)));
+    ctx->n_entries = n_entries;
+    ctx->h_orders.assign(orders, orders + n_entries);
+    return SAT_OK;
+}
+
+int sat_db_upload_dense(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                        const uint8_t *tabs, const float *dmats, int pitch,
+                        const int64_t *db_ordinal)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (n_entries <= 0 || !orders || !tabs || !dmats || pitch < 1)
+        return fail(SAT_EINVAL, "empty database or null array");
+    std::vector<int64_t> off(n_entries);
+    int64_t cells = 0;
+    for (int e = 0; e < n_entries; e++) {
+        if (orders[e] < 1 || orders[e] > SAT_MAXDIM || orders[e] > pitch)
+            return fail(SAT_EINVAL, "entry %d: order %d outside 1..min(%d, pitch %d)", e, orders[e], SAT_MAXDIM, pitch);
+        off[e] = cells;
+        cells += (int64_t)orders[e] * (orders[e] + 1) / 2;
+    }
+    std::vector<uint8_t> tt((size_t)cells);
+    std::vector<float> dd((size_t)cells);
+    for (int e = 0; e < n_entries; e++) {
+        const uint8_t *t = tabs + (size_t)e * pitch * pitch;
+        const float *d = dmats + (size_t)e * pitch * pitch;
+        int64_t c = off[e];
+        for (int i = 0; i < orders[e]; i++)
+            for (int j = 0; j <= i; j++, c++) {
+                tt[(size_t)c] = t[(size_t)i * pitch + j];
+                dd[(size_t)c] = d[(size_t)i * pitch + j];
+            }
+    }
+    return sat_db_upload_packed(ctx, n_entries, orders, off.data(), tt.data(), dd.data(), db_ordinal);
+}
+
+int sat_db_size(const sat_ctx *ctx) { return ctx ? ctx->n_entries : 0; }
+
+int sat_query_set(sat_ctx *ctx, int n1, const uint8_t *qtab, const float *qdmat,
+                  int pitch, const uint8_t *qssetypes, uint32_t query_ordinal)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (n1 < 1 || n1 > SAT_MAXDIM || !qtab || !qdmat || !qssetypes || pitch < n1)
+        return fail(SAT_EINVAL, "bad query (n1=%d pitch=%d)", n1, pitch);
+    for (int i = 0; i < n1; i++)
+        if (qssetypes[i] > 3) return fail(SAT_EINVAL, "query SSE %d has type code %u (0..3 expected)", i, qssetypes[i]);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int n1p = n1 <= 16 ? 16 : (n1 <= 32 ? 32 : (n1 <= 64 ? 64 : 112));
+
+    // transposed cells: row k, column i holds (dmat1[i][k], mask of tab1[i][k]);
+    // diagonal and padding get a NaN distance so they never score
+    std::vector<uint2> cells((size_t)n1p * n1p);
+    for (int k = 0; k < n1p; k++)
+        for (int i = 0; i < n1p; i++) {
+            uint2 c;
+            c.x = 0x7FC00000u;
+            c.y = 0u;
+            if (k < n1 && i < n1 && k != i) {
+                float d = qdmat[(size_t)i * pitch + k];
+                memcpy(&c.x, &d, 4);
+                uint32_t code = qtab[(size_t)i * pitch + k];
+                c.y = (1u << ((code >> 4) & 15u)) | (1u << (16u + (code & 15u)));
+            }
+            cells[(size_t)k * n1p + i] = c;
+        }
+    std::vector<uint8_t> types((size_t)n1p, 0);
+    memcpy(types.data(), qssetypes, (size_t)n1);
+
+    dev_free(ctx->d_qcells);
+    dev_free(ctx->d_qtypes);
+    HIP_TRY(hipMalloc(&ctx->d_qcells, cells.size() * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&ctx->d_qtypes, types.size()));
+    HIP_TRY(hipMemcpy(ctx->d_qcells, cells.data(), cells.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_qtypes, types.data(), types.size(), hipMemcpyHostToDevice));
+    ctx->n1 = n1;
+    ctx->n1p = n1p;
+    ctx->query_ordinal = query_ordinal;
+    return SAT_OK;
+}
+
+int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart, void *hip_stream)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
+    return launch_search(ctx, lorder, lsoln, maxstart, s);
+}
+
+void *sat_device_scores(sat_ctx *ctx) { return ctx ? ctx->d_scores : nullptr; }
+void *sat_device_ssemaps(sat_ctx *ctx) { return ctx ? ctx->d_ssemaps : nullptr; }
+int sat_query_order(const sat_ctx *ctx) { return ctx ? ctx->n1 : 0; }
+
+int sat_sync(sat_ctx *ctx)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SAT_OK;
+}
+
+int sat_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart,
+               int32_t *scores, int32_t *ssemaps, double *kernel_ms)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (!scores) return fail(SAT_EINVAL, "scores buffer is null");
+    if (lsoln && !ssemaps) return fail(SAT_EINVAL, "lsoln set but ssemaps buffer is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    int rc = launch_search(ctx, lorder, lsoln, maxstart, ctx->stream);
+    if (rc != SAT_OK) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *kernel_ms = ms;
+    }
+    HIP_TRY(hipMemcpy(scores, ctx->d_scores, (size_t)ctx->n_entries * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (lsoln) {
+        const int n1 = ctx->n1;
+        std::vector<int8_t> packed((size_t)ctx->n_entries * n1);
+        HIP_TRY(hipMemcpy(packed.data(), ctx->d_ssemaps, packed.size(), hipMemcpyDeviceToHost));
+        for (int e = 0; e < ctx->n_entries; e++)
+            for (int i = 0; i < n1; i++)
+                ssemaps[(size_t)e * SAT_MAXDIM + i] = packed[(size_t)e * n1 + i];
+    }
+    return SAT_OK;
+}
+
+int sat_search_timed(sat_ctx *ctx, int lorder, int lsoln, int maxstart, int repeats,
+                     double *total_ms, double *kernel_ms)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (repeats < 1) return fail(SAT_EINVAL, "repeats must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < repeats; r++) {
+        int rc = launch_search(ctx, lorder, lsoln, maxstart, ctx->stream);
+        if (rc != SAT_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (total_ms) *total_ms = ms;
+    if (kernel_ms) *kernel_ms = ms;
+    return SAT_OK;
+}
+
+}  // extern "C"

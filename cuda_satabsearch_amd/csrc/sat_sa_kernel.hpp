@@ -1,0 +1,480 @@
+// sat_sa_kernel.hpp - the simulated-annealing tableau search kernel for gfx950 (CDNA4).
+//
+// One workgroup scores ONE database structure against the query; every lane runs an
+// independent restart chain (lane = restart, as the reference maps threadIdx to
+// restarts, K.cu:1012-1015), 100 Metropolis steps each.  Written from scratch for
+// 64-wide wavefronts and the 160 KB LDS; what it computes follows the reference
+// kernel body K.cu:924-1233 (K.cu = nvcc_src_current/cudaSaTabsearch_kernel.cu).
+//
+// Data layout in LDS (per workgroup)
+//   Dc   (n2+1) x (n2+1) 8-byte cells {f32 distance, u32 code mask} of the db entry,
+//        expanded from the packed lower triangle in HBM.  Row n2 and column n2 are a
+//        "null" SSE whose distance is NaN: an unmatched query SSE is represented as
+//        matched to the null SSE, so |d1 - NaN| <= 4 is false and the pair scores 0
+//        without any branch or predicate in the hot loop.
+//   Qc   query cells, TRANSPOSED: Qc[k*N1P + i] = {dmat1[i][k], mask(tab1[i][k])}.
+//        The hot loop reads column i = the moved SSE (different per lane) of row k
+//        (same for all lanes): consecutive i are consecutive 8-byte cells, so the
+//        64 lanes of a ds_read_b64 hit distinct banks or broadcast - conflict free.
+//        The diagonal distance is NaN, which removes the k == i term (K.cu:524,530).
+//   smap per-lane SSE map, one byte per query SSE, stored word-interleaved
+//        smap[w*T + tid]: word w of every lane is contiguous, so the uniform-k loop
+//        reads it conflict free and a lane's random byte access always lands in bank
+//        (tid mod 32) - also conflict free.
+//   bmap same layout, best map so far (LSOLN only).
+//   A code byte (hi nibble, lo nibble; parsetableaux.c:13-33) becomes the mask
+//        (1 << hi) | (1 << (16 + lo)); popcount(maskA & maskB) = number of equal
+//        nibbles, from which tscord's 2 / 1 / -2 (K.cu:306-332) is a 4-entry lookup.
+//
+// Free-SSE bookkeeping uses bit masks instead of the reference's int revmap[] and
+// 111-int candidate list (K.cu:677-714): occ = occupied db SSEs, mapped = matched
+// query SSEs, tmask[t] = db SSEs of type t.
+//
+// Random numbers: rocRAND Philox4x32-10 device API, one 4x32-bit block per SA step,
+// addressed by (seed, query, db ordinal, restart, step) - see oracle/sa_oracle.h for
+// the slot layout, which the CPU oracle restates bit for bit.
+//
+// Metropolis test: the reference evaluates expf((float)delta / temp) > u with glibc
+// expf on the host path (K.cu:1166).  temp takes 100 values and delta is a small
+// integer, so the host tabulates P[iter][-delta] = expf(-nd / temp_iter) with ITS
+// libm and the kernel compares table entries: accept decisions are those of the
+// host's expf, bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+#include <stdint.h>
+
+#define SAT_K_MAXITER 100
+#define SAT_K_STEP_BLOCK0 32          // Philox block of SA step 0 (oracle/sa_oracle.h)
+#define SAT_K_EPS 1.1e-7              // K.cu:67
+#define SAT_K_NO_SCORE (-99999)       // K.cu:1009
+
+struct SatKernelArgs {
+    // database shard (HBM)
+    const int32_t  *orders;       // [N]
+    const int64_t  *cell_off;     // [N] first packed cell
+    const uint8_t  *tab_tri;      // packed lower triangles, code bytes
+    const float    *dist_tri;     // packed lower triangles, distances
+    const uint32_t *ordinal;      // [N] db file-order ordinal (stream key)
+    const int32_t  *entry_list;   // entries handled by this launch (one per workgroup)
+    // query
+    const uint2    *qcells;       // [N1P][N1P] transposed cells {dist bits, mask}
+    const uint8_t  *qtypes;       // [N1P]
+    int32_t         n1;
+    // options
+    int32_t         lorder, lsoln, maxstart;
+    uint64_t        seed_q;       // seed + (query ordinal << 32)
+    // Metropolis table
+    const float    *ptab;         // ragged rows
+    const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
+    // results
+    int32_t        *scores;       // [N]
+    int8_t         *ssemaps;      // [N][n1], -1 = unmatched
+};
+
+namespace satk {
+
+// ---------------------------------------------------------------- small bit sets
+template <int W> struct Bits { uint32_t w[W]; };
+
+template <int W> __device__ __forceinline__ Bits<W> bits_zero()
+{
+    Bits<W> b;
+#pragma unroll
+    for (int i = 0; i < W; i++) b.w[i] = 0u;
+    return b;
+}
+// bits [0, pos) set; pos may be <= 0 or >= 32*W
+template <int W> __device__ __forceinline__ Bits<W> bits_below(int pos)
+{
+    Bits<W> b;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        int rel = pos - 32 * i;
+        uint32_t part = (uint32_t)((1ull << (rel < 0 ? 0 : (rel > 32 ? 32 : rel))) - 1ull);
+        b.w[i] = part;
+    }
+    return b;
+}
+template <int W> __device__ __forceinline__ void bits_set(Bits<W> &b, int pos)
+{
+#pragma unroll
+    for (int i = 0; i < W; i++) b.w[i] |= ((pos >> 5) == i) ? (1u << (pos & 31)) : 0u;
+}
+template <int W> __device__ __forceinline__ void bits_clear(Bits<W> &b, int pos)
+{
+#pragma unroll
+    for (int i = 0; i < W; i++) b.w[i] &= ~(((pos >> 5) == i) ? (1u << (pos & 31)) : 0u);
+}
+template <int W> __device__ __forceinline__ int bits_count(const Bits<W> &b)
+{
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) c += __popc(b.w[i]);
+    return c;
+}
+template <int W> __device__ __forceinline__ int bits_lowest(const Bits<W> &b)   // -1 if empty
+{
+    int r = -1;
+#pragma unroll
+    for (int i = W - 1; i >= 0; i--) r = b.w[i] ? 32 * i + (__ffs(b.w[i]) - 1) : r;
+    return r;
+}
+template <int W> __device__ __forceinline__ int bits_highest(const Bits<W> &b)  // -1 if empty
+{
+    int r = -1;
+#pragma unroll
+    for (int i = 0; i < W; i++) r = b.w[i] ? 32 * i + (31 - __clz(b.w[i])) : r;
+    return r;
+}
+// position of the r-th (0-based, ascending) set bit of a non-zero word with > r bits
+__device__ __forceinline__ int word_select(uint32_t v, int r)
+{
+    // branch-free rank select by halving: counts of the low half decide the side
+    uint32_t a = v - ((v >> 1) & 0x55555555u);
+    uint32_t b = (a & 0x33333333u) + ((a >> 2) & 0x33333333u);
+    uint32_t c = (b + (b >> 4)) & 0x0F0F0F0Fu;
+    uint32_t d = (c + (c >> 8)) & 0x00FF00FFu;
+    int pos = 0;
+    int t = (int)(d & 0xFFu);
+    if (r >= t) { pos = 16; r -= t; }
+    t = (int)((c >> pos) & 0xFu);
+    if (r >= t) { pos += 8; r -= t; }
+    t = (int)((b >> pos) & 0x7u);
+    if (r >= t) { pos += 4; r -= t; }
+    t = (int)((a >> pos) & 0x3u);
+    if (r >= t) { pos += 2; r -= t; }
+    t = (int)((v >> pos) & 0x1u);
+    if (r >= t) { pos += 1; }
+    return pos;
+}
+template <int W> __device__ __forceinline__ int bits_select(const Bits<W> &b, int r)
+{
+    int pos = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        int c = __popc(b.w[i]);
+        bool here = !found && r < c;
+        pos = here ? 32 * i + word_select(b.w[i], r) : pos;
+        found = found || here;
+        r -= c;
+    }
+    return pos;
+}
+
+// ---------------------------------------------------------------- cells and scores
+__device__ __forceinline__ uint32_t code_mask(uint32_t code)
+{
+    return (1u << ((code >> 4) & 15u)) | (1u << (16u + (code & 15u)));
+}
+
+// tscord (K.cu:306-332) gated by the SSE-distance test (K.cu:432, 524, 530):
+// 0 when the distances differ by more than 4 A (or either is the NaN of a null SSE /
+// the query diagonal), else 2 / 1 / -2 for two / one / no equal nibbles.
+__device__ __forceinline__ int pair_score(uint2 q, uint2 d)
+{
+    float diff = __uint_as_float(q.x) - __uint_as_float(d.x);
+    bool ok = fabsf(diff) <= 4.0f;
+    int m = __popc(q.y & d.y) + 1;
+    m = ok ? m : 0;
+    // nibble lookup: m = 0 -> 0, 1 -> -2, 2 -> 1, 3 -> 2
+    return __builtin_amdgcn_sbfe(0x21E0, (unsigned)(m << 2), 4u);
+}
+
+// ---------------------------------------------------------------- random streams
+// Block `block` of the chain's Philox stream through the rocRAND device API:
+// key = seed_q, counter = (block, 0, subsequence lo, subsequence hi).
+__device__ __forceinline__ uint4 philox_block(uint64_t seed_q, uint64_t subsequence, uint32_t block)
+{
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed_q, subsequence, 4ull * block, &st);
+    return rocrand4(&st);
+}
+__device__ __forceinline__ float to_uniform(uint32_t v)
+{
+    return rocrand_device::detail::uniform_distribution(v);   // (0, 1], rocrand_uniform.h:65-68
+}
+// (int)((u - EPS) * n) evaluated in double, as K.cu:1042 and K.cu:710 do
+__device__ __forceinline__ int scaled_index(float u, int n)
+{
+    return (int)(((double)u - SAT_K_EPS) * (double)n);
+}
+
+// LDS byte size of one workgroup
+__host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int threads, bool lsoln, bool q_in_lds)
+{
+    size_t n1w = (size_t)((n1 + 3) >> 2);
+    size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
+    dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
+    size_t bytes = dcells * 8;
+    if (q_in_lds) bytes += n1w * 4 * (size_t)n1p * 8;
+    bytes += n1w * threads * 4 * (lsoln ? 2 : 1);
+    bytes += 16 * 4;                                          // tmask[4][<=4]
+    bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
+    bytes += 8 * 8;                                           // reduction scratch (<= 8 waves... 4 used)
+    return bytes;
+}
+
+}  // namespace satk
+
+// N1P: pitch of the query cell matrix (>= 4*ceil(n1/4)); M2W: 32-bit words of a db-side
+// bit set (n2 <= 32*M2W); QLDS: query cells staged in LDS (else read through L1/L2).
+template <int N1P, int M2W, bool QLDS>
+__global__ void __launch_bounds__(256)
+sat_sa_kernel(const SatKernelArgs a)
+{
+    using namespace satk;
+    constexpr int M1W = (N1P + 31) / 32;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    const int e = a.entry_list[blockIdx.x];
+    const int n1 = a.n1;
+    const int n2 = a.orders[e];
+    const int n2p = n2 + 1;
+    const int n1w = (n1 + 3) >> 2;
+    const int NULLJ = n2;                       // the null db SSE
+    const bool lsoln = a.lsoln != 0;
+
+    // ---- carve LDS (must match satk::lds_bytes)
+    size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
+    dcells = (dcells + 1) & ~(size_t)1;
+    uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);
+    uint2 *QcL = Dc + dcells;
+    uint32_t *smap = reinterpret_cast<uint32_t *>(QcL + (QLDS ? (size_t)n1w * 4 * N1P : 0));
+    uint32_t *bmap = smap + (size_t)n1w * T;
+    uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * T : 0);
+    uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
+    const uint2 *Qc = QLDS ? QcL : a.qcells;
+
+    // ---- stage the db entry: packed lower triangle (HBM) -> full cell matrix (LDS)
+    {
+        const uint8_t *tt = a.tab_tri + a.cell_off[e];
+        const float *dd = a.dist_tri + a.cell_off[e];
+        const int total = n2p * n2p;
+        for (int c = tid; c < total; c += T) {
+            int j = c / n2p;
+            int l = c - j * n2p;
+            uint2 cell;
+            if (j < n2 && l < n2) {
+                int hi = j > l ? j : l, lo = j > l ? l : j;
+                int t = hi * (hi + 1) / 2 + lo;
+                cell.x = __float_as_uint(dd[t]);
+                cell.y = code_mask(tt[t]);
+            } else {
+                cell.x = 0x7FC00000u;   // NaN: the null SSE never passes the distance test
+                cell.y = 0u;
+            }
+            Dc[c] = cell;
+        }
+        if (tid < 16) tmask[tid] = 0u;
+        for (int i = tid; i < N1P; i += T) qtypes[i] = a.qtypes[i];
+        if (QLDS) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.qcells);
+            uint4 *dst = reinterpret_cast<uint4 *>(QcL);
+            const int vecs = n1w * 4 * N1P / 2;
+            for (int c = tid; c < vecs; c += T) dst[c] = src[c];
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n2; j += T) {
+        int t = a.tab_tri[a.cell_off[e] + (int64_t)j * (j + 1) / 2 + j] & 3;   // diagonal = SSE type
+        atomicOr(&tmask[t * 4 + (j >> 5)], 1u << (j & 31));
+    }
+    __syncthreads();
+
+    uint8_t *smap_b = reinterpret_cast<uint8_t *>(smap);
+    uint8_t *bmap_b = reinterpret_cast<uint8_t *>(bmap);
+    // byte k of this lane's map lives at ((k>>2)*T + tid)*4 + (k&3)
+    auto map_byte_addr = [&](int k) -> int { return (((k >> 2) * T + tid) << 2) + (k & 3); };
+
+    const uint64_t subseq_lo = (uint64_t)a.ordinal[e];
+    int best = SAT_K_NO_SCORE;
+    uint32_t best_restart = 0xFFFFFFFFu;
+    bool any = false;
+
+    for (int restart = tid; restart < a.maxstart; restart += T) {
+        any = true;
+        const uint64_t subseq = subseq_lo | ((uint64_t)(uint32_t)restart << 32);
+
+        // ---- random initial map (thinit, K.cu:588-648): order preserving, types respected
+        Bits<M1W> mapped = bits_zero<M1W>();
+        Bits<M2W> occ = bits_zero<M2W>();
+        {
+            const uint32_t nullword = (uint32_t)NULLJ * 0x01010101u;
+            for (int w = 0; w < n1w; w++) smap[w * T + tid] = nullword;
+            int j = 0;
+            bool stopped = false;
+            for (int i0 = 0; i0 < n1; i0 += 4) {
+                uint4 r = philox_block(a.seed_q, subseq, (uint32_t)(i0 >> 2));
+                uint32_t rv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int i = i0 + s;
+                    if (i < n1) {
+                        float u = to_uniform(rv[s]);
+                        if (!stopped && u < 0.5f) {
+                            const int t = qtypes[i];
+                            Bits<M2W> cand, below = bits_below<M2W>(j);
+#pragma unroll
+                            for (int w = 0; w < M2W; w++) cand.w[w] = tmask[t * 4 + w] & ~below.w[w];
+                            int jj = bits_lowest<M2W>(cand);
+                            if (jj < 0) {
+                                stopped = true;              // K.cu:633-638: give up, no more draws used
+                            } else {
+                                smap_b[map_byte_addr(i)] = (uint8_t)jj;
+                                bits_set<M1W>(mapped, i);
+                                bits_set<M2W>(occ, jj);
+                                j = jj + 1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- full score of the initial map (tmscord, K.cu:396-440)
+        int score = 0;
+        for (int i = 0; i < n1 - 1; i++) {
+            const int j = smap_b[map_byte_addr(i)];
+            const uint2 *drow = Dc + j * n2p;
+            for (int kw = (i + 1) >> 2; kw < n1w; kw++) {
+                const uint32_t word = smap[kw * T + tid];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int k = kw * 4 + s;
+                    if (k > i) {                                  // wave-uniform
+                        const int l = (word >> (8 * s)) & 0xFF;
+                        score += pair_score(Qc[k * N1P + i], drow[l]);
+                    }
+                }
+            }
+        }
+        if (score > best) {
+            best = score;
+            best_restart = (uint32_t)restart;
+            if (lsoln)
+                for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * T + tid];
+        }
+
+        // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
+        for (int iter = 0; iter < SAT_K_MAXITER; iter++) {
+            const uint4 r = philox_block(a.seed_q, subseq, (uint32_t)(SAT_K_STEP_BLOCK0 + iter));
+
+            // which query SSE moves (K.cu:1037-1042)
+            const int ssei = scaled_index(to_uniform(r.x), n1);
+            const int oldj = smap_b[map_byte_addr(ssei)];
+
+            // candidate db SSEs: free, same type, inside the order window (K.cu:1053-1086)
+            int startj = 0, endj = n2;
+            if (a.lorder) {
+                Bits<M1W> upto = bits_below<M1W>(ssei + 1), lowpart, highpart;
+#pragma unroll
+                for (int w = 0; w < M1W; w++) {
+                    lowpart.w[w] = mapped.w[w] & upto.w[w];
+                    highpart.w[w] = mapped.w[w] & ~upto.w[w];
+                }
+                const int p = bits_highest<M1W>(lowpart);
+                const int q = bits_lowest<M1W>(highpart);
+                const int pimg = smap_b[map_byte_addr(p < 0 ? 0 : p)];
+                const int qimg = smap_b[map_byte_addr(q < 0 ? 0 : q)];
+                startj = p < 0 ? n2 : pimg;                      // no mapped predecessor: empty window
+                endj = (ssei == n1 - 1) ? n2 : (q < 0 ? -1 : qimg);   // K.cu:1064-1077
+            }
+            Bits<M2W> cand;
+            {
+                const int t = qtypes[ssei];
+                Bits<M2W> lo = bits_below<M2W>(startj), hi = bits_below<M2W>(endj);
+#pragma unroll
+                for (int w = 0; w < M2W; w++)
+                    cand.w[w] = tmask[t * 4 + w] & ~occ.w[w] & hi.w[w] & ~lo.w[w];
+            }
+            const int cnt = bits_count<M2W>(cand);
+            int newj = NULLJ;                                     // no candidate: the SSE becomes unmatched
+            if (cnt == 1) {
+                newj = bits_lowest<M2W>(cand);                    // K.cu:701-702, no draw
+            } else if (cnt > 1) {
+                const int pick = scaled_index(to_uniform(r.y), cnt);   // K.cu:705-711
+                newj = bits_select<M2W>(cand, pick);
+            }
+
+            // score change (deltasd, K.cu:502-535)
+            const uint2 *qcol = Qc + ssei;
+            const uint2 *orow = Dc + oldj * n2p;
+            const uint2 *nrow = Dc + newj * n2p;
+            int delta = 0;
+            for (int kw = 0; kw < n1w; kw++) {
+                const uint32_t word = smap[kw * T + tid];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int k = kw * 4 + s;
+                    const int l = (word >> (8 * s)) & 0xFF;
+                    const uint2 q = qcol[k * N1P];
+                    delta += pair_score(q, nrow[l]) - pair_score(q, orow[l]);
+                }
+            }
+            const int newscore = score + delta;
+
+            // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
+            if (newscore > best) {
+                best = newscore;
+                best_restart = (uint32_t)restart;
+                if (lsoln) {
+                    for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * T + tid];
+                    bmap_b[map_byte_addr(ssei)] = (uint8_t)newj;
+                }
+            }
+
+            // Metropolis: accept iff expf(delta / temp) > u, via the host-built table
+            const float u = to_uniform(r.z);
+            const int rowoff = a.prow[2 * iter], rowmax = a.prow[2 * iter + 1];
+            const int nd = -delta;
+            float p = 0.0f;
+            if (delta > 0) p = 2.0f;                              // expf(x > 0) > 1 >= u
+            else if (nd <= rowmax) p = a.ptab[rowoff + nd];
+            if (p > u) {
+                score = newscore;
+                smap_b[map_byte_addr(ssei)] = (uint8_t)newj;
+                if (oldj != NULLJ) bits_clear<M2W>(occ, oldj);
+                if (newj != NULLJ) {
+                    bits_set<M2W>(occ, newj);
+                    bits_set<M1W>(mapped, ssei);
+                } else {
+                    bits_clear<M1W>(mapped, ssei);
+                }
+            }
+        }
+    }
+
+    // ---- arg-max over restarts; ties go to the lowest restart index, which is the
+    // first restart that reaches the maximum in the reference's sequential order
+    // (strict '>' at K.cu:1024, 1137, 1211)
+    unsigned long long key = any
+        ? (((unsigned long long)(uint32_t)(best + 0x40000000)) << 32) | (0xFFFFFFFFu - best_restart)
+        : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long other = __shfl_xor(key, off, 64);
+        key = other > key ? other : key;
+    }
+    const int wave = tid >> 6, nwaves = (T + 63) >> 6;
+    if ((tid & 63) == 0) red[wave] = key;
+    __syncthreads();
+    unsigned long long win = red[0];
+    for (int w = 1; w < nwaves; w++) win = red[w] > win ? red[w] : win;
+
+    const uint32_t win_restart = 0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu);
+    if (tid == 0) a.scores[e] = (int)(uint32_t)(win >> 32) - 0x40000000;
+    if (lsoln && any && best_restart == win_restart &&
+        ((((unsigned long long)(uint32_t)(best + 0x40000000)) << 32) | (0xFFFFFFFFu - best_restart)) == win) {
+        int8_t *out = a.ssemaps + (size_t)e * n1;
+        for (int i = 0; i < n1; i++) {
+            int j = bmap_b[map_byte_addr(i)];
+            out[i] = (int8_t)(j == NULLJ ? -1 : j);
+        }
+    }
+}

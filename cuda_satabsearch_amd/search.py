@@ -1,0 +1,146 @@
+"""GPU search: thin object wrapper over the C ABI (include/satabsearch.h).
+
+Argument names and meaning follow the reference kernel contract
+(nvcc_src_current/cudaSaTabsearch_kernel.cu:756-802): lorder, lsoln, maxstart,
+scores per db entry, ssemap[entry][query SSE] = matched db SSE or -1.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import SatError
+from .structures import StructSet
+
+MAXDIM = _native.MAXDIM
+DEFAULT_MAXSTART = 128   # saparams.h:40
+DEFAULT_SEED = 1234      # cudaSaTabsearch.cu:263, :871
+
+
+def device_count():
+    return int(_native.device_lib().sat_device_count())
+
+
+class Searcher:
+    """One HIP device, one resident database shard, one current query."""
+
+    def __init__(self, device=0, seed=DEFAULT_SEED):
+        self._lib = _native.device_lib()
+        self._ctx = self._lib.sat_ctx_create(int(device), int(seed))
+        if not self._ctx:
+            raise SatError(self._lib.sat_last_error().decode())
+        self.device = int(device)
+        self.n_entries = 0
+        self.n1 = 0
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.sat_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SatError(f"[{rc}] {self._lib.sat_last_error().decode()}")
+
+    # ---- database -----------------------------------------------------------
+    def upload(self, db: StructSet, db_ordinal=None):
+        """Upload a (shard of a) database.  db_ordinal[e] = position of entry e in the
+        whole database's file order; it keys the random streams so that sharding does
+        not change results.  Default: 0..N-1."""
+        n = len(db)
+        ordinal = None
+        if db_ordinal is not None:
+            ordinal = np.ascontiguousarray(db_ordinal, dtype=np.int64)
+            if ordinal.shape[0] != n:
+                raise ValueError("db_ordinal length mismatch")
+        self._check(self._lib.sat_db_upload_packed(
+            self._ctx, n, db.orders.ctypes.data, db.cell_off.ctypes.data, db.tab.ctypes.data,
+            db.dist.ctypes.data, ordinal.ctypes.data if ordinal is not None else None))
+        self.n_entries = n
+        self._orders = db.orders.copy()
+
+    def upload_dense(self, orders, tabs, dmats, pitch, db_ordinal=None):
+        orders = np.ascontiguousarray(orders, dtype=np.int32)
+        tabs = np.ascontiguousarray(tabs, dtype=np.uint8)
+        dmats = np.ascontiguousarray(dmats, dtype=np.float32)
+        ordinal = None if db_ordinal is None else np.ascontiguousarray(db_ordinal, dtype=np.int64)
+        self._check(self._lib.sat_db_upload_dense(
+            self._ctx, orders.shape[0], orders.ctypes.data, tabs.ctypes.data, dmats.ctypes.data, int(pitch),
+            ordinal.ctypes.data if ordinal is not None else None))
+        self.n_entries = int(orders.shape[0])
+        self._orders = orders.copy()
+
+    # ---- query --------------------------------------------------------------
+    def set_query(self, qtab, qdmat, qssetypes=None, query_ordinal=0):
+        """qtab / qdmat: dense [n1, P] matrices (P >= n1); SSE types default to the
+        tableau diagonal (cudaSaTabsearch.cu:410-412)."""
+        qtab = np.ascontiguousarray(qtab, dtype=np.uint8)
+        qdmat = np.ascontiguousarray(qdmat, dtype=np.float32)
+        n1, pitch = qtab.shape[0], qtab.shape[1]
+        if qdmat.shape != qtab.shape:
+            raise ValueError("qtab and qdmat shapes differ")
+        if qssetypes is None:
+            qssetypes = np.ascontiguousarray(np.diagonal(qtab)[:n1])
+        qssetypes = np.ascontiguousarray(qssetypes, dtype=np.uint8)
+        self._check(self._lib.sat_query_set(self._ctx, n1, qtab.ctypes.data, qdmat.ctypes.data, pitch,
+                                            qssetypes.ctypes.data, int(query_ordinal)))
+        self.n1 = n1
+
+    def set_query_from(self, queries: StructSet, s, query_ordinal=None):
+        t, d = queries.dense(s)
+        self.set_query(t, d, queries.ssetypes(s), s if query_ordinal is None else query_ordinal)
+
+    # ---- search -------------------------------------------------------------
+    def search(self, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART):
+        """Returns (scores int32[N], ssemaps int32[N, 111] or None, kernel_ms)."""
+        scores = np.empty(self.n_entries, np.int32)
+        ssemaps = np.full((self.n_entries, MAXDIM), -1, np.int32) if lsoln else None
+        ms = C.c_double(0.0)
+        self._check(self._lib.sat_search(self._ctx, int(bool(lorder)), int(bool(lsoln)), int(maxstart),
+                                         scores.ctypes.data, ssemaps.ctypes.data if lsoln else None,
+                                         C.byref(ms)))
+        return scores, ssemaps, ms.value
+
+    def search_async(self, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART, stream=None):
+        """Queue the search (no sync, no copy); results stay in device memory."""
+        self._check(self._lib.sat_search_async(self._ctx, int(bool(lorder)), int(bool(lsoln)), int(maxstart),
+                                               C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        self._check(self._lib.sat_sync(self._ctx))
+
+    def search_timed(self, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART, repeats=1):
+        """HIP-event time of `repeats` back-to-back searches on the launch stream (ms)."""
+        total, kern = C.c_double(0.0), C.c_double(0.0)
+        self._check(self._lib.sat_search_timed(self._ctx, int(bool(lorder)), int(bool(lsoln)), int(maxstart),
+                                               int(repeats), C.byref(total), C.byref(kern)))
+        return total.value, kern.value
+
+    def device_scores_ptr(self):
+        return self._lib.sat_device_scores(self._ctx)
+
+    def device_scores_tensor(self):
+        """int32 torch tensor aliasing the context's device score buffer (for RCCL gathers)."""
+        import torch
+
+        class _Holder:
+            pass
+
+        h = _Holder()
+        h.__cuda_array_interface__ = {
+            "shape": (self.n_entries,), "typestr": "<i4", "data": (int(self.device_scores_ptr()), False),
+            "version": 3, "strides": None,
+        }
+        return torch.as_tensor(h, device=f"cuda:{self.device}")

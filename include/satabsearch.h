@@ -1,0 +1,151 @@
+/*
+ * satabsearch.h - C ABI of the MI355X tableau-search library (libsatabsearch.so).
+ *
+ * This is the drop-in boundary for ONE path of stivalaa/cuda_satabsearch: the
+ * simulated-annealing scoring of one query against every database structure.
+ * Plain C: pointers and sizes only, no HIP / torch / C++ types.  Each entry
+ * point names the reference interface it stands in for (paths relative to the
+ * reference tree, H.cu = nvcc_src_current/cudaSaTabsearch.cu,
+ * K.cu = nvcc_src_current/cudaSaTabsearch_kernel.cu).
+ *
+ * Ownership: the caller owns every host buffer it passes; the context owns all
+ * device memory.  Threading: one context per host thread; no globals.
+ * Errors: every int-returning call yields 0 on success and a negative SAT_E*
+ * code otherwise; sat_last_error() has the text.  Nothing in the library calls
+ * exit() or abort().  There is no CPU fallback: without a usable HIP device
+ * sat_ctx_create() fails with SAT_ENODEVICE.
+ */
+#ifndef SATABSEARCH_H
+#define SATABSEARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAT_ABI_VERSION   1
+#define SAT_MAXDIM        111    /* saparams.h:15 (MAXDIM): largest structure order        */
+#define SAT_MAXITER       100    /* saparams.h:33 (MAXITER): SA steps per restart           */
+#define SAT_DEFAULT_SEED  1234   /* H.cu:263, :871                                           */
+
+#define SAT_OK          0
+#define SAT_EINVAL     -1   /* bad argument (order out of range, bad type code, ...)        */
+#define SAT_ENODEVICE  -2   /* no HIP device / device index out of range                    */
+#define SAT_ENOMEM     -3   /* host or device allocation failed                             */
+#define SAT_EDEVICE    -4   /* a HIP call or the kernel launch failed (H.cu:1067-1073)      */
+#define SAT_ESTATE     -5   /* call order violated (search before upload / query)           */
+
+typedef struct sat_ctx sat_ctx;
+
+/* Message of the most recent failure on this thread ("" if none). */
+const char *sat_last_error(void);
+
+/* Library ABI version (SAT_ABI_VERSION it was built with). */
+int sat_abi_version(void);
+
+/* Number of visible HIP devices; replaces cudaGetDeviceCount, H.cu:805-812. */
+int sat_device_count(void);
+
+/*
+ * Create a context on HIP device `device` (the reference picks one device and
+ * calls cudaSetDevice, H.cu:813-865, then allocates and seeds one RNG state per
+ * thread with init_rng, H.cu:258-264, 896-922).  Here the random streams are
+ * counter based, so `seed` is all the state there is: chain (query ordinal, db
+ * ordinal, restart) draws from its own Philox4x32-10 stream.
+ * Returns NULL on failure.
+ */
+sat_ctx *sat_ctx_create(int device, uint64_t seed);
+
+/* Release every device and host resource of the context (H.cu:1117-1126, 1326-1337). */
+void sat_ctx_destroy(sat_ctx *ctx);
+
+/*
+ * Upload a database shard given as packed lower triangles (the layout the
+ * library's own reader produces, sat_parse.h):
+ *   n_entries          structures in this shard
+ *   orders[e]          number of SSEs of entry e, 1..SAT_MAXDIM
+ *   cell_off[e]        index of entry e's first cell in tab_tri / dist_tri
+ *   tab_tri, dist_tri  cell (i,j), j <= i, at cell_off[e] + i*(i+1)/2 + j;
+ *                      diagonal of tab_tri = SSE type code 0..3, off-diagonal =
+ *                      two-nibble tableau code (parsetableaux.c:13-33)
+ *   db_ordinal[e]      position of entry e in the whole database's file order
+ *                      (keys the random streams, so results do not depend on
+ *                      how the database is sharded over GPUs); NULL = e
+ * Replaces the cudaMalloc3D + cudaMemcpy3D of the dense 96x96 / 111x111 slots,
+ * H.cu:924-967 and 1135-1177; both size classes go into the one packed store.
+ */
+int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                         const int64_t *cell_off, const uint8_t *tab_tri,
+                         const float *dist_tri, const int64_t *db_ordinal);
+
+/*
+ * Same, from the reference's dense host layout: entry e occupies
+ * pitch*pitch cells at tabs + e*pitch*pitch (row-major, symmetric), exactly the
+ * arrays read_database() returns (parsetableaux.c:317-506; pitch 96 or 111).
+ * Only the lower triangle is read.
+ */
+int sat_db_upload_dense(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                        const uint8_t *tabs, const float *dmats, int pitch,
+                        const int64_t *db_ordinal);
+
+/* Entries currently resident. */
+int sat_db_size(const sat_ctx *ctx);
+
+/*
+ * Set the query: dense n1 x n1 code and distance matrices with row pitch
+ * `pitch` (111 in the reference), SSE types in qssetypes[0..n1).  Replaces the
+ * four cudaMemcpy to the c_qn / c_qtab / c_qdmat / c_qssetypes device symbols,
+ * copyQueryToConstantMemory H.cu:486-558 and K.cu:118-121.  `query_ordinal` is
+ * the query's index in the run (second key of the random streams).
+ */
+int sat_query_set(sat_ctx *ctx, int n1, const uint8_t *qtab, const float *qdmat,
+                  int pitch, const uint8_t *qssetypes, uint32_t query_ordinal);
+
+/*
+ * Run the search for the current query over the resident shard and wait for it.
+ * Replaces the sa_tabsearch_gpu / sa_tabsearch_gpu_noshared launches, their
+ * cudaDeviceSynchronize and the result cudaMemcpy, H.cu:1036-1087, 1219-1253
+ * (kernel contract K.cu:756-802):
+ *   lorder     keep sequence order of matched SSEs (LORDER)
+ *   lsoln      also return the best SSE map (LSOLN)
+ *   maxstart   restarts per db entry (-r, default 128)
+ *   scores     [n_entries]            best score per entry, shard order
+ *   ssemaps    [n_entries * SAT_MAXDIM] or NULL; entry e's map at e*SAT_MAXDIM,
+ *              ssemaps[e*111 + i] = db SSE matched to query SSE i, or -1; only
+ *              written when lsoln != 0 (same layout as K.cu:797-800, 1232)
+ *   kernel_ms  (may be NULL) device time of the search kernels, launch -> sync,
+ *              the window the reference times (H.cu:1036-1077)
+ */
+int sat_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart,
+               int32_t *scores, int32_t *ssemaps, double *kernel_ms);
+
+/*
+ * Device-resident variant for callers that keep results on the GPU (bench.py,
+ * torch.distributed gather over RCCL): launches on `hip_stream` (a hipStream_t
+ * passed as void*, NULL = the context's own stream), does not synchronise and
+ * does not copy.  Results land in the context's device buffers:
+ *   sat_device_scores()   int32 [n_entries]
+ *   sat_device_ssemaps()  int8  [n_entries * sat_query_order()], -1 = unmatched,
+ *                         valid after a search with lsoln != 0
+ */
+int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart, void *hip_stream);
+void *sat_device_scores(sat_ctx *ctx);
+void *sat_device_ssemaps(sat_ctx *ctx);
+int sat_query_order(const sat_ctx *ctx);
+
+/* Wait for everything queued by sat_search_async on the context's stream. */
+int sat_sync(sat_ctx *ctx);
+
+/*
+ * Time `repeats` back-to-back searches with HIP events on the launch stream
+ * (inputs resident, no copies inside the window).  Returns total milliseconds
+ * in *total_ms and the dominant SA kernel's summed device time in *kernel_ms.
+ */
+int sat_search_timed(sat_ctx *ctx, int lorder, int lsoln, int maxstart, int repeats,
+                     double *total_ms, double *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SATABSEARCH_H */
