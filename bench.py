@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py - db-structure scorings/sec of the SA tableau search on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[3] / north_star target shape): one 32-SSE synthetic
+query against a synthetic database of 125 000 x N structures of 32 SSEs (N = 8 is the
+1M-entry configuration), r = 128 restarts x 100 SA steps per (query, entry) pair,
+LTYPE = T, LORDER = T, LSOLN = F.  The database is sharded contiguously, one shard per
+GPU / process; a STEP is one full search of the query over every shard followed by the
+one gather of the per-shard score arrays to rank 0 (RCCL over xGMI when N > 1).  Inputs
+are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `value` = (N x 125 000 x K) / max-over-ranks time.
+Extra objects: `roofline` (HBM-nominal, see DESIGN.md section 4: the path is VALU/LDS
+bound, the HBM fraction is reported because the contract asks for it) and, at N = 1,
+`cpu_baseline` (the reference's host path timed on this box's CPU on a bounded sample).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_ENTRIES = 125_000
+ORDER = 32
+MAXSTART = 128
+MAXITER = 100
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes_per_scoring(n2):
+    # 1 B code + 4 B distance per lower-triangle cell, + order + score
+    return 5 * n2 * (n2 + 1) // 2 + 4 + 4
+
+
+def cpu_baseline(db, q, sample_seconds=15.0):
+    """Time the reference host path on this machine's CPU on a bounded prefix of the same
+    database.  Prefers the reference's own sources compiled into oracle/_ref (kind
+    "reference"); otherwise the C restatement in oracle/ (kind "port").  One thread, one
+    sequential drand48 stream: the literal `-c` semantics."""
+    import cuda_satabsearch_amd as sat
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    qt, qd, qtypes = q
+    # size the sample from a short calibration run of the port
+    t0 = time.time()
+    oracle_lib.search(db, qt, qd, qtypes, True, False, MAXSTART, mode=oracle_lib.RNG_DRAND48,
+                      entries=np.arange(64))
+    per_entry = (time.time() - t0) / 64
+    n = int(max(256, min(len(db), sample_seconds / max(per_entry, 1e-6))))
+    sample = f"first {n} entries of the rank-0 shard, same query, r={MAXSTART}, single sequential drand48 stream"
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_oracle")
+    if os.path.exists(ref_bin):
+        with tempfile.TemporaryDirectory() as tmp:
+            sub = db.subset(np.arange(n))
+            sat.synth.write_ascii(sub, os.path.join(tmp, "db.ascii"))
+            qset = sat.StructSet.from_dense([len(qtypes)], [qt], [qd], ["SYNQ32"])
+            sat.synth.write_ascii(qset, os.path.join(tmp, "q.body"))
+            with open(os.path.join(tmp, "q.input"), "w") as f:
+                f.write("db.ascii\nT T F\n")
+                f.write(open(os.path.join(tmp, "q.body")).read())
+            with open(os.path.join(tmp, "q.input")) as fin:
+                p = subprocess.run([ref_bin, "-c", "-r", str(MAXSTART)], stdin=fin, cwd=tmp,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            ms = [float(l.split()[3]) for l in p.stderr.splitlines() if l.startswith("host execution time")]
+            if p.returncode == 0 and ms:
+                return {"value": n / (sum(ms) / 1e3), "unit": "db-structure scorings/sec", "cores": 1,
+                        "kind": "reference", "sample": sample + " (reference sources compiled into oracle/_ref, g++ -O3)"}
+    t0 = time.time()
+    oracle_lib.search(db, qt, qd, qtypes, True, False, MAXSTART, mode=oracle_lib.RNG_DRAND48, entries=np.arange(n))
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "db-structure scorings/sec", "cores": 1, "kind": "port",
+            "sample": sample + " (oracle/sa_oracle.c, gcc -O3)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--entries", type=int, default=PER_GPU_ENTRIES, help="db entries per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import cuda_satabsearch_amd as sat
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: this rank's contiguous shard of the synthetic database + the query
+    n_local = args.entries
+    total = n_local * world
+    db = sat.synth.make_db(n_local, ORDER, ORDER, first_index=rank * n_local, total=total)
+    qt, qd, qtypes = sat.synth.make_query(ORDER)
+    searcher = sat.Searcher(local_rank)
+    searcher.upload(db, db_ordinal=np.arange(rank * n_local, (rank + 1) * n_local))
+    searcher.set_query(qt, qd, qtypes, 0)
+    scores_dev = searcher.device_scores_tensor()
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty_like(scores_dev) for _ in range(world)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        searcher.search_async(True, False, MAXSTART, stream=stream)
+        if world > 1:
+            dist.gather(scores_dev, gather_list, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[2 * k].record()                       # same stream the SA kernel is launched on
+        searcher.search_async(True, False, MAXSTART, stream=stream)
+        ev[2 * k + 1].record()
+        if world > 1:
+            dist.gather(scores_dev, gather_list, dst=0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(args.steps)]
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        scorings = total * args.steps
+        value = scorings / elapsed
+        kavg_ms = float(np.mean(kernel_ms))
+        abytes = algorithmic_bytes_per_scoring(ORDER) * n_local
+        achieved = abytes / (kavg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "db-structure scorings/sec (query x db pairs/sec) at r=128",
+            "value": value, "unit": "db-structure scorings/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32 scores over f32 distance / u8 tableau-code lookups",
+            "data": "synthetic (seeded generator, cuda_satabsearch_amd/synth.py)",
+            "config": {"workload": "32-SSE synthetic query x %d-entry synthetic db (32 SSEs per entry; %d per GPU), "
+                                   "r=128 restarts x 100 SA steps, LTYPE=T LORDER=T LSOLN=F, contiguous db shards, "
+                                   "one gather of int32 scores per step" % (total, n_local),
+                       "query_sses": ORDER, "db_entries": total, "restarts": MAXSTART,
+                       "parallelism": "db-shard x%d" % world},
+            "sa_steps_per_sec": value * MAXSTART * MAXITER,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sat_sa_kernel<32,1,true>", "kernel_ms_avg": kavg_ms,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "note": "nominal bound only: 2648 B per scoring against 12 800 dependent SA steps; "
+                                 "the kernel is VALU/LDS-issue bound (DESIGN.md section 4)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(db, (qt, qd, qtypes))
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    searcher.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,282 @@
+"""GPU parity tests (-m gpu): the HIP kernel, called through the C ABI, against the CPU
+oracle running the same counter-based Philox streams.  Integer work: bit-exact scores
+and bit-identical SSE maps.  (The oracle itself is pinned to the reference's `-c` output
+in test_oracle_golden.py; the only difference between the two oracle modes is the
+random stream.)"""
+import os
+
+import numpy as np
+import pytest
+
+import cuda_satabsearch_amd as sat
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def searcher():
+    assert sat.device_count() >= 1, "GPU tests need a HIP device (no CPU path exists)"
+    s = sat.Searcher(0)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def small_db(golden_dir):
+    return sat.StructSet.read(os.path.join(golden_dir, "tableauxdistmatrixdb.small.ascii"))
+
+
+def load_query(golden_dir, name, index=0):
+    qs = sat.StructSet.read(os.path.join(golden_dir, name), "query", skip_header_lines=2)
+    t, d = qs.dense(index)
+    return t, d, qs.ssetypes(index)
+
+
+def check(searcher, db, q, lorder, lsoln, maxstart, entries=None, query_ordinal=0, seed=1234):
+    qt, qd, qtypes = q
+    searcher.set_query(qt, qd, qtypes, query_ordinal)
+    scores, maps, _ = searcher.search(lorder, lsoln, maxstart)
+    idx = np.arange(len(db)) if entries is None else np.asarray(entries)
+    oscores, omaps, _ = oracle_lib.search(db, qt, qd, qtypes, lorder, lsoln, maxstart, entries=idx,
+                                          query_ordinal=query_ordinal, seed=seed)
+    bad = np.nonzero(scores[idx] != oscores)[0]
+    assert bad.size == 0, f"{bad.size} score mismatches, first at entry {idx[bad[:5]]}: gpu {scores[idx][bad[:5]]} oracle {oscores[bad[:5]]}"
+    if lsoln:
+        assert np.array_equal(maps[idx], omaps), "SSE maps differ"
+    return scores, maps
+
+
+# ---------------------------------------------------------------- reference example data
+@pytest.mark.parametrize("qfile,qi,lorder,lsoln", [
+    ("c1_d1ubia_small.input", 0, True, False),      # BASELINE configs[1]: 8 SSEs, T T F
+    ("d2phlb1.input", 0, True, True),               # 19 SSEs with solution maps
+    ("d2phlb1.input", 0, False, True),              # LORDER = F window [0, n2)
+    ("multiquery.input", 1, True, False),           # 13 SSEs
+    ("d1twfa_.input", 0, True, True),               # 101 SSEs: widest query class
+])
+def test_small_db_bit_exact(searcher, small_db, golden_dir, qfile, qi, lorder, lsoln):
+    searcher.upload(small_db)
+    check(searcher, small_db, load_query(golden_dir, qfile, qi), lorder, lsoln, 128)
+
+
+@pytest.mark.parametrize("maxstart", [1, 63, 64, 100, 128, 300, 1024])
+def test_restart_counts(searcher, small_db, golden_dir, maxstart):
+    """maxstart below / not a multiple of / above the workgroup size (lanes loop)."""
+    searcher.upload(small_db)
+    entries = np.arange(0, len(small_db), 7)
+    check(searcher, small_db, load_query(golden_dir, "d2phlb1.input"), True, True, maxstart, entries=entries)
+
+
+def test_known_answer_rows(searcher, golden_dir):
+    """Near-self match of the 1-entry example db: score 54 and the identity map, as the
+    reference prints for d1ubia_.input (expected/d1ubia_.r128.out)."""
+    db = sat.StructSet.read(os.path.join(golden_dir, "tableauxdistmatrixdb.test.ascii"))
+    searcher.upload(db)
+    q = load_query(golden_dir, "d1ubia_.input")
+    scores, maps = check(searcher, db, q, True, True, 128)
+    assert scores[0] == 54
+    assert list(maps[0][:8]) == list(range(8))
+    lines = sat.report.result_lines(db.names, db.orders, scores, 8, maps)
+    expected = open(os.path.join(ROOT, "tests/golden/expected/d1ubia_.r128.out")).read().splitlines()[3:]
+    assert lines == expected
+
+
+# ---------------------------------------------------------------- every size class
+@pytest.fixture(scope="module")
+def wide_db():
+    """Orders uniform on [1, 111]: every db bucket and bit-set width."""
+    return sat.synth.make_db(230, 1, 111, sort=False, seed=77)
+
+
+@pytest.mark.parametrize("n1", [1, 2, 5, 16, 17, 32, 33, 64, 65, 96, 111])
+def test_all_query_and_db_classes(searcher, wide_db, n1):
+    searcher.upload(wide_db)
+    rng = np.random.default_rng(n1)
+    src = int(rng.choice(np.nonzero(wide_db.orders >= n1)[0]))
+    t, d = wide_db.dense(src)
+    sel = np.sort(rng.choice(int(wide_db.orders[src]), size=n1, replace=False))
+    q = (t[np.ix_(sel, sel)].copy(), d[np.ix_(sel, sel)].copy(), np.diagonal(t)[sel].copy())
+    scores, _ = check(searcher, wide_db, q, True, True, 128)
+    if n1 >= 5:
+        assert scores[src] == scores.max()        # the planted source is the best hit
+    check(searcher, wide_db, q, False, False, 64, entries=np.arange(0, len(wide_db), 3))
+
+
+def test_large_everything_lds_spill_regime(searcher):
+    """BASELINE configs[4] shape: >= 64-SSE query, LSOLN = T, db entries up to 111 SSEs:
+    the query cells no longer fit beside the db entry in LDS."""
+    db = sat.synth.make_db(48, 90, 111, sort=True, seed=5)
+    searcher.upload(db)
+    q = sat.synth.planted_query(db, 40, keep=0.95)
+    assert len(q[2]) >= 64
+    check(searcher, db, q, True, True, 128)
+    check(searcher, db, q, True, True, 256)
+
+
+# ---------------------------------------------------------------- keys of the streams
+def test_sharding_does_not_change_results(searcher):
+    db = sat.synth.make_db(600, 8, 32)
+    q = sat.synth.planted_query(db, 123)
+    searcher.upload(db)
+    whole, wmaps = check(searcher, db, q, True, True, 128, entries=np.arange(0, 600, 11))
+    for lo, hi in [(0, 150), (150, 600)]:
+        shard = db.subset(np.arange(lo, hi))
+        searcher.upload(shard, db_ordinal=np.arange(lo, hi))
+        searcher.set_query(*q, 0)
+        s, m, _ = searcher.search(True, True, 128)
+        assert np.array_equal(s, whole[lo:hi]) and np.array_equal(m, wmaps[lo:hi])
+
+
+def test_query_ordinal_and_seed_key_the_streams(searcher, small_db, golden_dir):
+    q = load_query(golden_dir, "d2phlb1.input")
+    searcher.upload(small_db)
+    entries = np.arange(0, len(small_db), 5)
+    s0, _ = check(searcher, small_db, q, True, False, 128, entries=entries, query_ordinal=0)
+    s3, _ = check(searcher, small_db, q, True, False, 128, entries=entries, query_ordinal=3)
+    assert not np.array_equal(s0, s3)
+    with sat.Searcher(0, seed=99) as other:
+        other.upload(small_db)
+        s99, _ = check(other, small_db, q, True, False, 128, entries=entries, seed=99)
+    assert not np.array_equal(s0, s99)
+
+
+def test_dense_upload_equals_packed(searcher, small_db, golden_dir):
+    q = load_query(golden_dir, "c1_d1ubia_small.input")
+    searcher.upload(small_db)
+    searcher.set_query(*q, 0)
+    a, _, _ = searcher.search(True, False, 128)
+    pitch = 96
+    tabs = np.zeros((len(small_db), pitch, pitch), np.uint8)
+    dmats = np.zeros((len(small_db), pitch, pitch), np.float32)
+    for s in range(len(small_db)):
+        tabs[s], dmats[s] = small_db.dense(s, pitch)
+    searcher.upload_dense(small_db.orders, tabs, dmats, pitch)
+    searcher.set_query(*q, 0)
+    b, _, _ = searcher.search(True, False, 128)
+    assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- edge cases
+def test_degenerate_structures(searcher):
+    """1-SSE structures, a query whose SSE types do not occur in an entry, all-'??' codes."""
+    orders = np.array([1, 1, 2, 3, 4], np.int32)
+    tabs = np.zeros((5, 4, 4), np.uint8)
+    dmats = np.zeros((5, 4, 4), np.float32)
+    tabs[1, 0, 0] = 1                                   # single helix
+    tabs[2][[0, 1], [0, 1]] = [1, 1]; tabs[2, 1, 0] = tabs[2, 0, 1] = 0x44
+    tabs[3][[0, 1, 2], [0, 1, 2]] = [3, 3, 3]           # only 3-10 helices
+    for s in range(5):
+        n = orders[s]
+        dmats[s][:n, :n] = 5.0 + np.arange(n * n).reshape(n, n) % 7
+        dmats[s] = np.tril(dmats[s], -1) + np.tril(dmats[s], -1).T
+    tabs[4][[0, 1, 2, 3], [0, 1, 2, 3]] = [0, 1, 2, 3]
+    tabs[4][np.tril_indices(4, -1)] = 0x23
+    tabs[4] = np.tril(tabs[4]) + np.tril(tabs[4], -1).T
+    db = sat.StructSet.from_dense(orders, tabs, dmats)
+    searcher.upload(db)
+    qt = np.array([[0, 0x23, 0x44], [0x23, 1, 0x23], [0x44, 0x23, 2]], np.uint8)
+    qd = np.array([[0, 6, 9], [6, 1, 7], [9, 7, 2]], np.float32)
+    for lorder in (True, False):
+        check(searcher, db, (qt, qd, np.array([0, 1, 2], np.uint8)), lorder, True, 128)
+    one = (np.array([[1]], np.uint8), np.array([[1.0]], np.float32), np.array([1], np.uint8))
+    check(searcher, db, one, True, True, 64)
+
+
+def test_distance_threshold_boundary(searcher):
+    """|d1 - d2| <= 4.0f is evaluated in float, exactly as the reference does: pairs
+    engineered to sit on both sides of the boundary after float rounding."""
+    rng = np.random.default_rng(3)
+    n = 12
+    types = rng.integers(0, 2, n).astype(np.uint8)
+    base = np.round(rng.uniform(5, 40, (n, n)), 3).astype(np.float32)
+    base = np.tril(base, -1) + np.tril(base, -1).T
+    codes = rng.choice([0x00, 0x11, 0x23, 0x32], size=(n, n)).astype(np.uint8)
+    codes = np.tril(codes, -1) + np.tril(codes, -1).T
+    codes[np.arange(n), np.arange(n)] = types
+    tabs, dmats = [], []
+    for off in (4.0, 3.999, 4.001, np.float32(4.0) + np.float32(2.0 ** -21), -4.0):
+        d = (base + np.float32(off)).astype(np.float32)
+        d[np.arange(n), np.arange(n)] = types
+        tabs.append(codes); dmats.append(np.abs(d))
+    db = sat.StructSet.from_dense(np.full(5, n, np.int32), np.array(tabs), np.array(dmats))
+    searcher.upload(db)
+    qd = base.copy(); qd[np.arange(n), np.arange(n)] = types
+    scores, _ = check(searcher, db, (codes, qd, types), True, True, 128)
+    assert len(set(scores.tolist())) > 1
+
+
+def test_error_behaviour():
+    with sat.Searcher(0) as s:
+        with pytest.raises(sat.SatError, match="no database"):
+            s.search()
+        db = sat.synth.make_db(4, 4, 8)
+        s.upload(db)
+        with pytest.raises(sat.SatError, match="no query"):
+            s.search()
+        bad = sat.StructSet(np.array([200], np.int32), ["x"], np.array([0], np.int64),
+                            np.zeros(20100, np.uint8), np.zeros(20100, np.float32))
+        with pytest.raises(sat.SatError, match="order"):
+            s.upload(bad)
+        qt, qd, qtypes = sat.synth.make_query(6)
+        s.upload(db)
+        s.set_query(qt, qd, qtypes)
+        with pytest.raises(sat.SatError, match="maxstart"):
+            s.search(maxstart=0)
+    with pytest.raises(sat.SatError, match="out of range"):
+        sat.Searcher(4096)
+
+
+# ---------------------------------------------------------------- reference -c stream (T3)
+def test_statistically_consistent_with_reference_host_output(searcher, small_db, golden_dir):
+    """The reference's `-c` run draws from ONE sequential drand48 stream, which no parallel
+    run can replay (its own GPU path does not either).  Against its golden stdout the GPU
+    result must sit inside the reference's own seed-to-seed spread measured in
+    SURVEY.md section 4 (8-SSE query, r=128: ~190 / 586 entries differ, max |diff| 7) and
+    show no systematic deficit."""
+    exp = open(os.path.join(ROOT, "tests/golden/expected/c1_d1ubia_small.r128.out")).read().splitlines()[3:]
+    ref = np.array([int(l.split()[1]) for l in exp])
+    searcher.upload(small_db)
+    searcher.set_query(*load_query(golden_dir, "c1_d1ubia_small.input"), 0)
+    gpu, _, _ = searcher.search(True, False, 128)
+    diff = gpu - ref
+    assert (diff != 0).mean() < 0.45
+    assert np.abs(diff).max() <= 10
+    assert abs(diff.mean()) < 0.25
+    rank_corr = np.corrcoef(np.argsort(np.argsort(gpu)), np.argsort(np.argsort(ref)))[0, 1]
+    assert rank_corr > 0.95
+    # 19-SSE query at r=4096 against the stdout the reference recorded in 2013.  The
+    # reference's own recorded GPU and host logs of this very job differ on 207 / 586
+    # entries with max |diff| 19; same bar here, and no bias.
+    exp4k = open(os.path.join(ROOT, "tests/golden/expected/recorded_2013_d2phlb1.r4096.out")).read().splitlines()
+    ref4k = {l.split()[0]: int(l.split()[1]) for l in exp4k if not l.startswith("#")}
+    searcher.set_query(*load_query(golden_dir, "d2phlb1.input"), 0)
+    gpu4k, _, _ = searcher.search(True, False, 4096)
+    d4k = np.array([gpu4k[i] - ref4k[n] for i, n in enumerate(small_db.names)])
+    assert (d4k != 0).mean() < 0.45 and np.abs(d4k).max() <= 20
+    assert abs(d4k.mean()) < 0.5
+
+
+# ---------------------------------------------------------------- full benchmark size
+def test_full_size_properties():
+    """BASELINE configs[2]/[3] scale on one GPU: 100k entries, 32-SSE query, r=128.  The
+    oracle cannot run this in test time, so: (a) a random sample of entries is compared
+    with the oracle bit for bit, (b) two runs are identical, (c) the planted source entry
+    is the top hit, (d) every score is within the bounds the scoring function allows."""
+    n = 100_000
+    db = sat.synth.make_db(n, 32)
+    q = sat.synth.planted_query(db, 54_321, keep=1.0, jitter=0.5)
+    n1 = len(q[2])
+    with sat.Searcher(0) as s:
+        s.upload(db)
+        s.set_query(*q, 0)
+        a, _, ms = s.search(True, False, 128)
+        b, _, _ = s.search(True, False, 128)
+    assert np.array_equal(a, b)
+    assert a.argmax() == 54_321
+    assert a.max() <= 2 * n1 * (n1 - 1) // 2 and a.min() >= -2 * n1 * (n1 - 1) // 2
+    sample = np.random.default_rng(0).choice(n, 48, replace=False)
+    osc, _, _ = oracle_lib.search(db, *q, True, False, 128, entries=sample)
+    assert np.array_equal(a[sample], osc)
+    print(f"100k x 32-SSE: {ms:.1f} ms -> {n / ms * 1e3:.0f} scorings/s")

@@ -1,0 +1,79 @@
+"""The CPU oracle against the reference's own outputs (not gpu).
+
+expected/*.out were produced by the reference's sources compiled in place
+(oracle/_ref, tests/golden/make_golden.sh); recorded_2013_* is the stdout the reference
+ships from a real 2013 run.  Byte-for-byte equality pins search + reader + statistics +
+printing of the restatement.
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "oracle", "oracle_cli")
+EXPECTED = os.path.join(ROOT, "tests", "golden", "expected")
+
+
+def run_cli(golden_dir, input_name, *args):
+    with open(os.path.join(golden_dir, input_name)) as fin:
+        p = subprocess.run([CLI, "-c", *args], stdin=fin, cwd=golden_dir, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    return p.stdout
+
+
+CASES = [
+    ("d1ubia_.input", "d1ubia_.r128.out", ["-r", "128"]),                  # 1-entry db, T T T
+    ("d1ae6h1.input", "d1ae6h1.r128.out", ["-r", "128"]),
+    ("d2phlb1.input2", "d2phlb12.r128.out", ["-r", "128"]),                # LSOLN=T solution pairs
+    ("d2phlb1.input3", "d2phlb13.r128.out", ["-r", "128"]),
+    ("1qlp_sheetbc.input", "1qlp_sheetbc.r128.out", ["-r", "128"]),        # substructure motif query
+    ("c1_d1ubia_small.input", "c1_d1ubia_small.r128.out", ["-r", "128"]),  # BASELINE configs[0]
+    ("d2phlb1.input", "d2phlb1.r128.out", ["-r", "128"]),
+    ("d2phlb1_TFT.input", "d2phlb1_TFT.r128.out", ["-r", "128"]),          # LORDER=F, LSOLN=T
+    ("d2phlb1_TTT.input", "d2phlb1_TTT.r128.out", ["-r", "128"]),
+    ("d1twfa_.input", "d1twfa_.r128.out", ["-r", "128"]),                  # 101 SSEs, >=100 A parse quirk
+    ("d1twfa_.input", "d1twfa_.r16.out", ["-r", "16"]),
+    ("multiquery.input", "multiquery.r128.out", ["-r", "128"]),            # one stream across 3 queries
+]
+
+
+@pytest.mark.parametrize("inp,exp,args", CASES, ids=[c[1] for c in CASES])
+def test_oracle_cli_matches_reference_build(golden_dir, inp, exp, args):
+    out = run_cli(golden_dir, inp, *args)
+    with open(os.path.join(EXPECTED, exp), "rb") as f:
+        assert out == f.read()
+
+
+def test_oracle_step_trace_matches_reference_debug_build(golden_dir):
+    """Every SA step's proposal (ssei, startj, endj, newj) and map, one restart."""
+    out = run_cli(golden_dir, "d1ubia_.input", "-r", "1", "-t")
+    with open(os.path.join(EXPECTED, "d1ubia_.r1.trace.stdout"), "rb") as f:
+        assert out == f.read()
+
+
+def test_oracle_reproduces_recorded_2013_run(golden_dir):
+    """old/nvcc_src_cuda5/cpu_cudaSaTabsearch.o1462445: `-c -r4096 < d2phlb1.input` on
+    the 2013 sources, whose small/large class boundary was 32 SSEs (-m 32).  ~30 s."""
+    out = run_cli(golden_dir, "d2phlb1.input", "-r", "4096", "-m", "32")
+    with open(os.path.join(EXPECTED, "recorded_2013_d2phlb1.r4096.out"), "rb") as f:
+        assert out == f.read()
+
+
+def test_q_mode_equals_inline_query(golden_dir):
+    """-q takes SIDs of db members; the same structure given inline must give the same
+    rows (options are fixed T T F in -q mode, cudaSaTabsearch.cu:633-635)."""
+    import cuda_satabsearch_amd as sat
+    db = sat.StructSet.read(os.path.join(golden_dir, "tableauxdistmatrixdb.small.ascii"))
+    sid = db.names[3]
+    p = subprocess.run([CLI, "-c", "-r", "8", "-q", "tableauxdistmatrixdb.small.ascii"],
+                       input=(sid.upper() + "\n").encode(), cwd=golden_dir, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    sub = db.subset([3])
+    inline = os.path.join(golden_dir, "_inline.input")
+    body = os.path.join(golden_dir, "_inline.body")
+    sat.synth.write_ascii(sub, body)
+    with open(inline, "w") as f:
+        f.write("tableauxdistmatrixdb.small.ascii\nT T F\n" + open(body).read())
+    out2 = run_cli(golden_dir, "_inline.input", "-r", "8")
+    assert p.stdout == out2

@@ -1,0 +1,49 @@
+"""Unit checks of the oracle's building blocks (not gpu)."""
+import numpy as np
+
+import oracle_lib
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10."""
+    assert oracle_lib.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle_lib.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle_lib.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_drand48_restatement_matches_libc():
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.drand48.restype = ctypes.c_double
+    libc.srand48(1234)
+    x = oracle_lib.lib().sa_oracle_srand48(1234)
+    for _ in range(1000):
+        x = (0x5DEECE66D * x + 0xB) & ((1 << 48) - 1)
+        assert libc.drand48() == x / 2.0 ** 48
+
+
+def test_uniform_conversion_range():
+    f = oracle_lib.lib().sa_oracle_u32_to_uniform
+    assert f(0) == np.float32(2.0 ** -32)
+    assert f(0xFFFFFFFF) == 1.0
+    assert 0.49 < f(0x7FFFFFFF) <= 0.5
+
+
+def test_pair_score_table():
+    ps = oracle_lib.lib().sa_oracle_pair_score
+    assert ps(0x23, 0x23) == 2 and ps(0x23, 0x21) == 1 and ps(0x23, 0x13) == 1 and ps(0x23, 0x10) == -2
+    assert ps(0x44, 0x44) == 2 and ps(0x44, 0x04) == 1 and ps(0x44, 0x00) == -2
+
+
+def test_philox_mode_is_schedule_independent():
+    """Scores of an entry depend only on (seed, query, db ordinal): any subset / order of
+    entries gives the same per-entry result - the property multi-GPU sharding relies on."""
+    import cuda_satabsearch_amd as sat
+    db = sat.synth.make_db(40, 5, 20)
+    qt, qd, qtypes = sat.synth.planted_query(db, 30)
+    full, fmaps, _ = oracle_lib.search(db, qt, qd, qtypes, True, True, 32)
+    sub = np.array([30, 3, 17])
+    part, pmaps, _ = oracle_lib.search(db, qt, qd, qtypes, True, True, 32, entries=sub)
+    assert np.array_equal(part, full[sub]) and np.array_equal(pmaps, fmaps[sub])
+    assert full[30] == full.max() and full[30] > 20
