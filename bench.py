@@ -122,10 +122,11 @@ def main():
     gather_list = None
     if world > 1 and rank == 0:
         gather_list = [torch.empty_like(scores_dev) for _ in range(world)]
-    stream = torch.cuda.current_stream().cuda_stream
+    # launch on torch's current stream: the RCCL gather and the timing events follow the kernel
+    searcher.use_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        searcher.search_async(True, False, MAXSTART, stream=stream)
+        searcher.search_async(True, False, MAXSTART)
         if world > 1:
             dist.gather(scores_dev, gather_list, dst=0)
 
@@ -142,7 +143,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[2 * k].record()                       # same stream the SA kernel is launched on
-        searcher.search_async(True, False, MAXSTART, stream=stream)
+        searcher.search_async(True, False, MAXSTART)
         ev[2 * k + 1].record()
         if world > 1:
             dist.gather(scores_dev, gather_list, dst=0)

@@ -56,7 +56,8 @@ template <typename T> void dev_free(T *&p)
 struct sat_ctx {
     int device = 0;
     uint64_t seed = SAT_DEFAULT_SEED;
-    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;   // created with the context
+    hipStream_t stream = nullptr;       // where work is queued (own_stream unless sat_use_stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // database shard
@@ -144,7 +145,7 @@ template <int N1P> kernel_fn pick_m2w(int m2w, bool qlds)
         if (m2w == 2) return sat_sa_kernel<N1P, 2, true>;
         return sat_sa_kernel<N1P, 4, true>;
     }
-    if constexpr (N1P >= 64) {
+    if constexpr (N1P >= 32) {
         if (m2w == 1) return sat_sa_kernel<N1P, 1, false>;
         if (m2w == 2) return sat_sa_kernel<N1P, 2, false>;
         return sat_sa_kernel<N1P, 4, false>;
@@ -206,7 +207,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
         // threads: one lane per restart up to 256; shrink until the workgroup fits the LDS
         int threads = (maxstart + 63) / 64 * 64;
         if (threads > 256) threads = 256;
-        bool qlds = true;
+        bool qlds = !(getenv("SAT_EXP_QGLOBAL") && ctx->n1p >= 32);   // experiment switch
         size_t lds = 0;
         for (;;) {
             lds = satk::lds_bytes(ctx->n1, ctx->n1p, n2max, threads, lsoln != 0, qlds);
@@ -266,7 +267,8 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
     ctx->seed = seed;
     auto init = [&]() -> int {
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
         HIP_TRY(hipEventCreate(&ctx->ev0));
         HIP_TRY(hipEventCreate(&ctx->ev1));
         return build_metropolis_table(ctx);
@@ -282,7 +284,7 @@ void sat_ctx_destroy(sat_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     free_db(ctx);
     dev_free(ctx->d_qcells);
     dev_free(ctx->d_qtypes);
@@ -290,7 +292,7 @@ void sat_ctx_destroy(sat_ctx *ctx)
     dev_free(ctx->d_prow);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -432,11 +434,28 @@ int sat_query_set(sat_ctx *ctx, int n1, const uint8_t *qtab, const float *qdmat,
     return SAT_OK;
 }
 
-int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart, void *hip_stream)
+int sat_use_stream(sat_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(SAT_EINVAL, "null context");
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
-    return launch_search(ctx, lorder, lsoln, maxstart, s);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return SAT_OK;
+}
+
+int sat_use_own_stream(sat_ctx *ctx)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
+    return SAT_OK;
+}
+
+int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    return launch_search(ctx, lorder, lsoln, maxstart, ctx->stream);
 }
 
 void *sat_device_scores(sat_ctx *ctx) { return ctx ? ctx->d_scores : nullptr; }

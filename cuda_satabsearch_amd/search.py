@@ -113,10 +113,18 @@ class Searcher:
                                          C.byref(ms)))
         return scores, ssemaps, ms.value
 
-    def search_async(self, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART, stream=None):
-        """Queue the search (no sync, no copy); results stay in device memory."""
-        self._check(self._lib.sat_search_async(self._ctx, int(bool(lorder)), int(bool(lsoln)), int(maxstart),
-                                               C.c_void_p(stream) if stream else None))
+    def use_stream(self, stream_handle):
+        """Queue all further work on the caller's HIP stream (0 / None = default stream),
+        e.g. torch.cuda.current_stream().cuda_stream."""
+        self._check(self._lib.sat_use_stream(self._ctx, C.c_void_p(int(stream_handle or 0))))
+
+    def use_own_stream(self):
+        self._check(self._lib.sat_use_own_stream(self._ctx))
+
+    def search_async(self, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART):
+        """Queue the search on the context's current stream (no sync, no copy); results
+        stay in device memory."""
+        self._check(self._lib.sat_search_async(self._ctx, int(bool(lorder)), int(bool(lsoln)), int(maxstart)))
 
     def sync(self):
         self._check(self._lib.sat_sync(self._ctx))

@@ -121,20 +121,30 @@ int sat_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart,
                int32_t *scores, int32_t *ssemaps, double *kernel_ms);
 
 /*
+ * Queue all further work of this context on the caller's stream (`hip_stream` is a
+ * hipStream_t passed as void*; NULL selects the device's default stream).  A context
+ * starts on a private non-blocking stream; sat_use_own_stream() goes back to it.
+ * Lets a caller order the search with its own copies / collectives (bench.py hands
+ * over torch's current stream so that the RCCL gather follows the kernel).
+ */
+int sat_use_stream(sat_ctx *ctx, void *hip_stream);
+int sat_use_own_stream(sat_ctx *ctx);
+
+/*
  * Device-resident variant for callers that keep results on the GPU (bench.py,
- * torch.distributed gather over RCCL): launches on `hip_stream` (a hipStream_t
- * passed as void*, NULL = the context's own stream), does not synchronise and
- * does not copy.  Results land in the context's device buffers:
+ * torch.distributed gather over RCCL): launches on the context's current stream,
+ * does not synchronise and does not copy.  Results land in the context's device
+ * buffers:
  *   sat_device_scores()   int32 [n_entries]
  *   sat_device_ssemaps()  int8  [n_entries * sat_query_order()], -1 = unmatched,
  *                         valid after a search with lsoln != 0
  */
-int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart, void *hip_stream);
+int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart);
 void *sat_device_scores(sat_ctx *ctx);
 void *sat_device_ssemaps(sat_ctx *ctx);
 int sat_query_order(const sat_ctx *ctx);
 
-/* Wait for everything queued by sat_search_async on the context's stream. */
+/* Wait for everything queued on the context's current stream. */
 int sat_sync(sat_ctx *ctx);
 
 /*
