@@ -207,7 +207,10 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
         // threads: one lane per restart up to 256; shrink until the workgroup fits the LDS
         int threads = (maxstart + 63) / 64 * 64;
         if (threads > 256) threads = 256;
-        bool qlds = !(getenv("SAT_EXP_QGLOBAL") && ctx->n1p >= 32);   // experiment switch
+        // query cells: through L1/L2 for 32-SSE-class queries and up (frees 8+ KB of LDS per
+        // workgroup: more resident waves), in LDS for the small class
+        bool qlds = ctx->n1p < 32;
+        if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || ctx->n1p < 32;
         size_t lds = 0;
         for (;;) {
             lds = satk::lds_bytes(ctx->n1, ctx->n1p, n2max, threads, lsoln != 0, qlds);

@@ -170,17 +170,21 @@ __device__ __forceinline__ uint32_t code_mask(uint32_t code)
     return (1u << ((code >> 4) & 15u)) | (1u << (16u + (code & 15u)));
 }
 
-// tscord (K.cu:306-332) gated by the SSE-distance test (K.cu:432, 524, 530):
-// 0 when the distances differ by more than 4 A (or either is the NaN of a null SSE /
-// the query diagonal), else 2 / 1 / -2 for two / one / no equal nibbles.
-__device__ __forceinline__ int pair_score(uint2 q, uint2 d)
+// tscord (K.cu:306-332) gated by the SSE-distance test (K.cu:432, 524, 530), biased by
+// +2 so that it is an unsigned byte: returns 2 when the distances differ by more than
+// 4 A (or either is the NaN of a null SSE / the query diagonal), else 4 / 3 / 0 for
+// two / one / no equal nibbles (= 2 + {2, 1, -2}).  Both sides of a move evaluate the
+// same number of terms, so the bias cancels in new - old; the full score subtracts it.
+// One v_perm_b32 does the 4-entry table lookup: selector byte 0 = 0..3 picks a byte of
+// the table, selector bytes 1..3 = 0x0C yield zero.
+#define SAT_K_TERM_BIAS 2
+__device__ __forceinline__ uint32_t pair_term(uint2 q, uint2 d)
 {
     float diff = __uint_as_float(q.x) - __uint_as_float(d.x);
     bool ok = fabsf(diff) <= 4.0f;
-    int m = __popc(q.y & d.y) + 1;
-    m = ok ? m : 0;
-    // nibble lookup: m = 0 -> 0, 1 -> -2, 2 -> 1, 3 -> 2
-    return __builtin_amdgcn_sbfe(0x21E0, (unsigned)(m << 2), 4u);
+    uint32_t sel = (uint32_t)__popc(q.y & d.y) + 0x0C0C0C01u;
+    sel = ok ? sel : 0x0C0C0C00u;
+    return __builtin_amdgcn_perm(0u, 0x04030002u, sel);
 }
 
 // ---------------------------------------------------------------- random streams
@@ -349,7 +353,7 @@ sat_sa_kernel(const SatKernelArgs a)
                     const int k = kw * 4 + s;
                     if (k > i) {                                  // wave-uniform
                         const int l = (word >> (8 * s)) & 0xFF;
-                        score += pair_score(Qc[k * N1P + i], drow[l]);
+                        score += (int)pair_term(Qc[k * N1P + i], drow[l]) - SAT_K_TERM_BIAS;
                     }
                 }
             }
@@ -406,7 +410,7 @@ sat_sa_kernel(const SatKernelArgs a)
             const uint2 *qcol = Qc + ssei;
             const uint2 *orow = Dc + oldj * n2p;
             const uint2 *nrow = Dc + newj * n2p;
-            int delta = 0;
+            uint32_t sum_new = 0, sum_old = 0;
             for (int kw = 0; kw < n1w; kw++) {
                 const uint32_t word = smap[kw * T + tid];
 #pragma unroll
@@ -414,9 +418,11 @@ sat_sa_kernel(const SatKernelArgs a)
                     const int k = kw * 4 + s;
                     const int l = (word >> (8 * s)) & 0xFF;
                     const uint2 q = qcol[k * N1P];
-                    delta += pair_score(q, nrow[l]) - pair_score(q, orow[l]);
+                    sum_new += pair_term(q, nrow[l]);
+                    sum_old += pair_term(q, orow[l]);
                 }
             }
+            const int delta = (int)sum_new - (int)sum_old;
             const int newscore = score + delta;
 
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
