@@ -119,16 +119,13 @@ def main():
     searcher.upload(db, db_ordinal=np.arange(rank * n_local, (rank + 1) * n_local))
     searcher.set_query(qt, qd, qtypes, 0)
     scores_dev = searcher.device_scores_tensor()
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty_like(scores_dev) for _ in range(world)]
     # launch on torch's current stream: the RCCL gather and the timing events follow the kernel
     searcher.use_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
         searcher.search_async(True, False, MAXSTART)
         if world > 1:
-            dist.gather(scores_dev, gather_list, dst=0)
+            sat.sharding.gather_to_rank0(scores_dev, total, world, rank, dist)
 
     def fence():
         torch.cuda.synchronize()
@@ -146,7 +143,7 @@ def main():
         searcher.search_async(True, False, MAXSTART)
         ev[2 * k + 1].record()
         if world > 1:
-            dist.gather(scores_dev, gather_list, dst=0)
+            sat.sharding.gather_to_rank0(scores_dev, total, world, rank, dist)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = [ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(args.steps)]

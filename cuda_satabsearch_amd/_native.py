@@ -19,7 +19,7 @@ ABI_SYMBOLS = (
     "sat_last_error", "sat_abi_version", "sat_device_count", "sat_ctx_create", "sat_ctx_destroy",
     "sat_db_upload_packed", "sat_db_upload_dense", "sat_db_size", "sat_query_set", "sat_search",
     "sat_search_async", "sat_device_scores", "sat_device_ssemaps", "sat_query_order", "sat_sync",
-    "sat_search_timed", "sat_use_stream", "sat_use_own_stream",
+    "sat_search_timed", "sat_use_stream", "sat_use_own_stream", "sat_results",
 )
 
 
@@ -69,6 +69,7 @@ def device_lib():
         lib.sat_search_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.sat_use_stream.argtypes = [C.c_void_p, C.c_void_p]
         lib.sat_use_own_stream.argtypes = [C.c_void_p]
+        lib.sat_results.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.sat_device_scores.argtypes = [C.c_void_p]
         lib.sat_device_scores.restype = C.c_void_p
         lib.sat_device_ssemaps.argtypes = [C.c_void_p]

@@ -63,9 +63,12 @@ def build_cli(force=False):
     bindir = os.path.join(PKG, "bin")
     os.makedirs(bindir, exist_ok=True)
     out = os.path.join(bindir, "satabsearch")
-    deps = [src, os.path.join(PKG, "libsatabsearch.so"), os.path.join(PKG, "libsathost.so")]
+    host_search = os.path.join(HOST, "sat_host_search.c")
+    deps = [src, host_search, os.path.join(HOST, "sat_host_search.h"),
+            os.path.join(PKG, "libsatabsearch.so"), os.path.join(PKG, "libsathost.so")]
     if force or _stale(out, deps):
-        _run([CC, "-O2", "-Wall", "-Wextra", "-I", INC, "-I", HOST, "-o", out, src,
+        # -O3 without fast-math or fma contraction: the host mode must round like the reference's
+        _run([CC, "-O3", "-ffp-contract=off", "-Wall", "-Wextra", "-I", INC, "-I", HOST, "-o", out, src, host_search,
               "-L", PKG, "-lsatabsearch", "-lsathost", "-lm", "-Wl,-rpath,$ORIGIN/.."])
     return out
 

@@ -1,0 +1,347 @@
+/*
+ * sat_main.c - the `satabsearch` command line: drop-in for `cudaSaTabsearch`.
+ *
+ * Same options, stdin grammar and stdout bytes as the reference's main
+ * (nvcc_src_current/cudaSaTabsearch.cu): options -c -q -r :605-626; "-q" SID list
+ * :631-664 (SIDs cut to 7 chars, options fixed T T F); inline mode header :667-694;
+ * LTYPE forced to T :696-700; SID lookup small class first :746-780; output = all
+ * queries over the small class (order <= 96), then all queries over the large class
+ * (97..111), three '#' header lines per (query, class) :1027-1030, rows :1102-1114 and
+ * :1255-1268 (the large pass of the GPU path prints two blanks before the p-value).
+ *
+ * Host code is plain C; the search itself goes through the C ABI of
+ * include/satabsearch.h (HIP kernel).  The reference is single-GPU (its TODO, :790);
+ * here the database is sharded contiguously over the visible GPUs (-g N), one context
+ * per GPU driven from this thread: launch on all, then collect in file order.  Results
+ * do not depend on N (the random streams are keyed by db ordinal).
+ *
+ * -c selects the host mode (csrc/host/sat_host_search.c): one CPU thread, one
+ * sequential drand48 stream, byte-identical to the reference's -c.  It is never a
+ * fallback: without -c a missing GPU is an error.
+ *
+ * Extensions: -g N (GPUs to use, default all visible), -s SEED (Philox seed, default 1234).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "satabsearch.h"
+#include "sat_gumbel.h"
+#include "sat_host_search.h"
+#include "sat_parse.h"
+
+#define MAX_GPUS 64
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static void usage(const char *prog)
+{
+    fprintf(stderr, "Usage: %s [-c] [-q dbfile] [-r restarts] [-g gpus] [-s seed]\n", prog);
+    fprintf(stderr, "  -c : run on host CPU not GPU card\n");
+    fprintf(stderr, "  -q dbfile : database is read from dbfile, list of query\n"
+                    "              ids is read from stdin\n");
+    fprintf(stderr, "  -r restarts : number of restarts. Default %d\n", 128);
+    fprintf(stderr, "  -g gpus : number of GPUs to shard the database over. Default all\n");
+    fprintf(stderr, "  -s seed : seed of the GPU random streams. Default %d\n", SAT_DEFAULT_SEED);
+    exit(1);
+}
+
+static void print_header(int ltype, int lorder, int lsoln, const char *qid, const char *dbfile)
+{
+    printf("# cudaSaTabsearch LTYPE = %c LORDER = %c LSOLN = %c\n",
+           ltype ? 'T' : 'F', lorder ? 'T' : 'F', lsoln ? 'T' : 'F');
+    printf("# QUERY ID = %-8s\n", qid);
+    printf("# DBFILE = %-80s\n", dbfile);
+}
+
+static void print_row(const char *name, int score, int n1, int n2, const int32_t *map, int lsoln,
+                      int wide_gap)
+{
+    double norm2score = sat_norm2(score, n1, n2);
+    double zscore = sat_z_gumbel_trunc(norm2score);
+    double pvalue = sat_pv_gumbel(zscore);
+    printf(wide_gap ? "%-8s %d %g %g  %g\n" : "%-8s %d %g %g %g\n", name, score, norm2score, zscore, pvalue);
+    if (lsoln)
+        for (int k = 0; k < n1; k++)
+            if (map[k] >= 0)
+                printf("%3d %3d\n", k + 1, map[k] + 1);
+}
+
+int main(int argc, char *argv[])
+{
+    char dbfile[SAT_MAX_LINE_LEN] = "";
+    char buf[SAT_MAX_LINE_LEN];
+    int use_gpu = 1, querydbmode = 0, maxstart = 128, want_gpus = 0;
+    unsigned long long seed = SAT_DEFAULT_SEED;
+    int ltype = 0, lorder = 0, lsoln = 0;
+    char cltype = 'F', clorder = 'F', clsoln = 'F';
+    int c;
+
+    while ((c = getopt(argc, argv, "cq:r:g:s:")) != -1) {
+        switch (c) {
+        case 'c': use_gpu = 0; break;
+        case 'q': querydbmode = 1; strncpy(dbfile, optarg, sizeof(dbfile) - 1); break;
+        case 'r': maxstart = atoi(optarg); break;
+        case 'g': want_gpus = atoi(optarg); break;
+        case 's': seed = strtoull(optarg, NULL, 0); break;
+        default: usage(argv[0]);
+        }
+    }
+    fprintf(stderr, "MAXDIM = %d\n", SAT_MAXDIM);
+
+    sat_struct_set queries, db;
+    sat_set_init(&queries);
+    sat_set_init(&db);
+    char *sid_list = NULL;
+    int num_queries = 0;
+
+    if (querydbmode) {
+        cltype = 'T'; ltype = 1;
+        clorder = 'T'; lorder = 1;
+        clsoln = 'F'; lsoln = 0;
+        while (!feof(stdin)) {
+            if (!fgets(buf, SAT_MAX_LINE_LEN, stdin))
+                break;
+            char *grown = (char *)realloc(sid_list, (size_t)(num_queries + 1) * (SAT_LABELSIZE + 1));
+            if (!grown) { fprintf(stderr, "realloc queryid_list failed\n"); exit(1); }
+            sid_list = grown;
+            char *sid = sid_list + (size_t)num_queries * (SAT_LABELSIZE + 1);
+            memset(sid, 0, SAT_LABELSIZE + 1);
+            strncpy(sid, buf, SAT_LABELSIZE);
+            sid[SAT_LABELSIZE - 1] = '\0';
+            size_t len = strlen(sid);
+            if (len && sid[len - 1] == '\n') sid[len - 1] = '\0';
+            num_queries++;
+        }
+    } else {
+        if (fscanf(stdin, "%s\n", dbfile) != 1) {
+            fprintf(stderr, "ERROR reading dbfilename from stdin\n");
+            exit(1);
+        }
+        if (fscanf(stdin, "%c %c %c\n", &cltype, &clorder, &clsoln) != 3) {
+            fprintf(stderr, "ERROR reading options from stdin\n");
+            exit(1);
+        }
+        ltype = cltype == 'T';
+        lorder = clorder == 'T';
+        lsoln = clsoln == 'T';
+        num_queries = sat_read_structures(stdin, &queries, "query");
+        if (num_queries < 0) {
+            fprintf(stderr, "ERROR loading query structures from stdin\n");
+            exit(1);
+        } else if (num_queries == 0) {
+            fprintf(stderr, "ERROR: no query structures found on stdin\n");
+            exit(1);
+        }
+        fprintf(stderr, "Read %d query structures\n", num_queries);
+    }
+    if (!ltype) {
+        fprintf(stderr, "WARNING: LTYPE is always set to T\n");
+        ltype = 1;
+    }
+
+    FILE *dbfp = fopen(dbfile, "r");
+    if (!dbfp) {
+        fprintf(stderr, "ERROR opening db file %s\n", dbfile);
+        exit(1);
+    }
+    fprintf(stderr, "Loading database...\n");
+    double t0 = now_ms();
+    int total = sat_read_structures(dbfp, &db, "database");
+    fclose(dbfp);
+    if (total < 0) {
+        fprintf(stderr, "ERROR loading database\n");
+        exit(1);
+    }
+    /* the two passes of the reference: small class then large class, file order inside */
+    int *cls_index[2], cls_count[2] = { 0, 0 };
+    cls_index[0] = (int *)malloc(sizeof(int) * (size_t)(total + 1));
+    cls_index[1] = (int *)malloc(sizeof(int) * (size_t)(total + 1));
+    if (!cls_index[0] || !cls_index[1]) { fprintf(stderr, "malloc failed\n"); exit(1); }
+    for (int s = 0; s < db.count; s++) {
+        int k = db.order[s] > SAT_MAXDIM_SMALL;
+        cls_index[k][cls_count[k]++] = s;
+    }
+    fprintf(stderr, "Loaded %d db entries (%d order > %d) in %f ms\n",
+            total, cls_count[1], SAT_MAXDIM_SMALL, now_ms() - t0);
+    if (total == 0) {
+        fprintf(stderr, "ERROR: empty database\n");
+        exit(1);
+    }
+
+    /* -q: SID -> db structure (small class searched first) */
+    const sat_struct_set *qsrc = querydbmode ? &db : &queries;
+    int *qindex = (int *)malloc(sizeof(int) * (size_t)(num_queries + 1));
+    for (int i = 0; i < num_queries; i++) {
+        qindex[i] = i;
+        if (!querydbmode)
+            continue;
+        const char *sid = sid_list + (size_t)i * (SAT_LABELSIZE + 1);
+        int found = -1;
+        for (int k = 0; k < 2 && found < 0; k++)
+            for (int d = 0; d < cls_count[k]; d++)
+                if (!strcasecmp(sid, sat_set_name(&db, cls_index[k][d]))) {
+                    found = cls_index[k][d];
+                    break;
+                }
+        if (found < 0) {
+            fprintf(stderr, "ERROR: query %s not found\n", sid);
+            exit(1);
+        }
+        qindex[i] = found;
+    }
+    fprintf(stderr, "maxstart = %d\n", maxstart);
+
+    int32_t *scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)total);
+    int32_t *ssemaps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)total) : NULL;
+    if (!scores || (lsoln && !ssemaps)) { fprintf(stderr, "malloc scores failed\n"); exit(1); }
+
+    if (!use_gpu) {
+        /* ---- host mode: class by class, query by query, ONE stream for everything ---- */
+        sat_host_stream stream;
+        sat_host_stream_seed(&stream, 1234);
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && cls_count[1] == 0)
+                break;
+            for (int qi = 0; qi < num_queries; qi++) {
+                const int qs = qindex[qi], n1 = qsrc->order[qs];
+                print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
+                fprintf(stderr, "Executing simulated annealing tableaux match kernel on host for query %s...\n",
+                        sat_set_name(qsrc, qs));
+                double t1 = now_ms();
+                if (sat_host_search(&db, cls_index[k], cls_count[k], qsrc, qs, lorder, lsoln, maxstart,
+                                    &stream, scores, ssemaps) != 0) {
+                    fprintf(stderr, "malloc failed in host search\n");
+                    exit(1);
+                }
+                double ms = now_ms() - t1;
+                fprintf(stderr, "host execution time %f ms\n", ms);
+                fprintf(stderr, "%f million iterations/sec\n",
+                        ((double)cls_count[k] * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
+                for (int d = 0; d < cls_count[k]; d++)
+                    print_row(sat_set_name(&db, cls_index[k][d]), scores[d], n1, db.order[cls_index[k][d]],
+                              ssemaps ? ssemaps + (size_t)d * SAT_MAXDIM : NULL, lsoln, 0);
+            }
+        }
+        return 0;
+    }
+
+    /* ---- GPU mode ---- */
+    int ndev = sat_device_count();
+    if (ndev <= 0) {
+        fprintf(stderr, "There is no usable HIP device (use -c for the host mode).\n");
+        exit(1);
+    }
+    fprintf(stderr, "found %d HIP devices\n", ndev);
+    int ngpu = want_gpus > 0 ? want_gpus : ndev;
+    if (ngpu > ndev) ngpu = ndev;
+    if (ngpu > MAX_GPUS) ngpu = MAX_GPUS;
+    if (ngpu > total) ngpu = total;
+
+    /* contiguous shards of the file order, equal entry counts (the cost of an entry is
+     * dominated by the query size, not the entry size) */
+    sat_ctx *ctx[MAX_GPUS];
+    int shard_begin[MAX_GPUS + 1];
+    int64_t *ordinal = (int64_t *)malloc(sizeof(int64_t) * (size_t)total);
+    for (int s = 0; s < total; s++) ordinal[s] = s;
+    t0 = now_ms();
+    for (int g = 0; g <= ngpu; g++)
+        shard_begin[g] = (int)((int64_t)total * g / ngpu);
+    for (int g = 0; g < ngpu; g++) {
+        ctx[g] = sat_ctx_create(g, seed);
+        if (!ctx[g]) {
+            fprintf(stderr, "sat_ctx_create(%d) failed: %s\n", g, sat_last_error());
+            exit(1);
+        }
+        int b = shard_begin[g], n = shard_begin[g + 1] - b;
+        /* a shard is a window of the packed arrays: rebase its cell offsets to the window */
+        int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+        if (!off) { fprintf(stderr, "malloc failed\n"); exit(1); }
+        for (int e = 0; e < n; e++) off[e] = db.cell_off[b + e] - db.cell_off[b];
+        int rc = sat_db_upload_packed(ctx[g], n, db.order + b, off, db.tab + db.cell_off[b],
+                                      db.dist + db.cell_off[b], ordinal + b);
+        free(off);
+        if (rc != SAT_OK) {
+            fprintf(stderr, "database upload to GPU %d failed: %s\n", g, sat_last_error());
+            exit(1);
+        }
+    }
+    fprintf(stderr, "Copied %d entries to %d GPU(s) in %f ms\n", total, ngpu, now_ms() - t0);
+
+    /* rows of the large class are printed after every query's small-class block */
+    int32_t *large_scores = NULL, *large_maps = NULL;
+    if (cls_count[1] > 0) {
+        large_scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)cls_count[1] * num_queries);
+        if (lsoln) large_maps = (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)cls_count[1] * num_queries);
+        if (!large_scores || (lsoln && !large_maps)) { fprintf(stderr, "malloc failed\n"); exit(1); }
+    }
+    uint8_t *qtab = (uint8_t *)calloc(SAT_MAXDIM * SAT_MAXDIM, 1);
+    float *qdmat = (float *)calloc(SAT_MAXDIM * SAT_MAXDIM, sizeof(float));
+    uint8_t qtypes[SAT_MAXDIM];
+    int exit_status = 0;
+
+    for (int qi = 0; qi < num_queries; qi++) {
+        const int qs = qindex[qi], n1 = qsrc->order[qs];
+        sat_set_expand(qsrc, qs, SAT_MAXDIM, qtab, qdmat);
+        for (int i = 0; i < n1; i++) qtypes[i] = qtab[i * SAT_MAXDIM + i];
+        print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
+        fprintf(stderr, "Executing simulated annealing tableaux match kernel on GPU for qid %s...\n",
+                sat_set_name(qsrc, qs));
+        double t1 = now_ms();
+        for (int g = 0; g < ngpu; g++) {
+            if (sat_query_set(ctx[g], n1, qtab, qdmat, SAT_MAXDIM, qtypes, (uint32_t)qi) != SAT_OK ||
+                sat_search_async(ctx[g], lorder, lsoln, maxstart) != SAT_OK) {
+                fprintf(stderr, "kernel launch failed: %s\n", sat_last_error());
+                exit_status = 1;
+                goto bye;
+            }
+        }
+        for (int g = 0; g < ngpu; g++) {
+            int b = shard_begin[g];
+            if (sat_results(ctx[g], lsoln, scores + b, ssemaps ? ssemaps + (size_t)b * SAT_MAXDIM : NULL) != SAT_OK) {
+                fprintf(stderr, "GPU %d search failed: %s\n", g, sat_last_error());
+                exit_status = 1;
+                goto bye;
+            }
+        }
+        double ms = now_ms() - t1;
+        fprintf(stderr, "GPU execution time %f ms\n", ms);
+        fprintf(stderr, "%f million iterations/sec\n",
+                ((double)total * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
+        for (int d = 0; d < cls_count[0]; d++) {
+            int s = cls_index[0][d];
+            print_row(sat_set_name(&db, s), scores[s], n1, db.order[s],
+                      ssemaps ? ssemaps + (size_t)s * SAT_MAXDIM : NULL, lsoln, 0);
+        }
+        for (int d = 0; d < cls_count[1]; d++) {
+            int s = cls_index[1][d];
+            large_scores[(size_t)qi * cls_count[1] + d] = scores[s];
+            if (lsoln)
+                memcpy(large_maps + ((size_t)qi * cls_count[1] + d) * SAT_MAXDIM,
+                       ssemaps + (size_t)s * SAT_MAXDIM, sizeof(int32_t) * SAT_MAXDIM);
+        }
+    }
+    if (cls_count[1] > 0)
+        for (int qi = 0; qi < num_queries; qi++) {
+            const int qs = qindex[qi], n1 = qsrc->order[qs];
+            print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
+            for (int d = 0; d < cls_count[1]; d++) {
+                int s = cls_index[1][d];
+                print_row(sat_set_name(&db, s), large_scores[(size_t)qi * cls_count[1] + d], n1, db.order[s],
+                          lsoln ? large_maps + ((size_t)qi * cls_count[1] + d) * SAT_MAXDIM : NULL, lsoln, 1);
+            }
+        }
+bye:
+    for (int g = 0; g < ngpu; g++)
+        sat_ctx_destroy(ctx[g]);
+    (void)cltype; (void)clorder; (void)clsoln;
+    return exit_status;
+}

@@ -473,6 +473,27 @@ int sat_sync(sat_ctx *ctx)
     return SAT_OK;
 }
 
+int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (!scores) return fail(SAT_EINVAL, "scores buffer is null");
+    if (lsoln && !ssemaps) return fail(SAT_EINVAL, "lsoln set but ssemaps buffer is null");
+    if (ctx->n_entries <= 0) return fail(SAT_ESTATE, "no database uploaded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(scores, ctx->d_scores, (size_t)ctx->n_entries * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (lsoln) {
+        const int n1 = ctx->n1;
+        if (!ctx->d_ssemaps) return fail(SAT_ESTATE, "no search with lsoln has run");
+        std::vector<int8_t> packed((size_t)ctx->n_entries * n1);
+        HIP_TRY(hipMemcpy(packed.data(), ctx->d_ssemaps, packed.size(), hipMemcpyDeviceToHost));
+        for (int e = 0; e < ctx->n_entries; e++)
+            for (int i = 0; i < n1; i++)
+                ssemaps[(size_t)e * SAT_MAXDIM + i] = packed[(size_t)e * n1 + i];
+    }
+    return SAT_OK;
+}
+
 int sat_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart,
                int32_t *scores, int32_t *ssemaps, double *kernel_ms)
 {
@@ -490,16 +511,7 @@ int sat_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart,
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         *kernel_ms = ms;
     }
-    HIP_TRY(hipMemcpy(scores, ctx->d_scores, (size_t)ctx->n_entries * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (lsoln) {
-        const int n1 = ctx->n1;
-        std::vector<int8_t> packed((size_t)ctx->n_entries * n1);
-        HIP_TRY(hipMemcpy(packed.data(), ctx->d_ssemaps, packed.size(), hipMemcpyDeviceToHost));
-        for (int e = 0; e < ctx->n_entries; e++)
-            for (int i = 0; i < n1; i++)
-                ssemaps[(size_t)e * SAT_MAXDIM + i] = packed[(size_t)e * n1 + i];
-    }
-    return SAT_OK;
+    return sat_results(ctx, lsoln, scores, ssemaps);
 }
 
 int sat_search_timed(sat_ctx *ctx, int lorder, int lsoln, int maxstart, int repeats,

@@ -126,6 +126,14 @@ class Searcher:
         stay in device memory."""
         self._check(self._lib.sat_search_async(self._ctx, int(bool(lorder)), int(bool(lsoln)), int(maxstart)))
 
+    def results(self, lsoln=False):
+        """Wait for a queued search_async and fetch (scores, ssemaps or None)."""
+        scores = np.empty(self.n_entries, np.int32)
+        ssemaps = np.full((self.n_entries, MAXDIM), -1, np.int32) if lsoln else None
+        self._check(self._lib.sat_results(self._ctx, int(bool(lsoln)), scores.ctypes.data,
+                                          ssemaps.ctypes.data if lsoln else None))
+        return scores, ssemaps
+
     def sync(self):
         self._check(self._lib.sat_sync(self._ctx))
 

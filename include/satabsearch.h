@@ -148,6 +148,15 @@ int sat_query_order(const sat_ctx *ctx);
 int sat_sync(sat_ctx *ctx);
 
 /*
+ * Wait for the queued search and copy its results to the host, same buffers and
+ * layout as sat_search (ssemaps may be NULL when lsoln == 0).  With sat_search_async
+ * this lets one host thread keep several devices busy (one context per GPU, the
+ * database sharded contiguously): launch on all, then collect from each - the
+ * multi-GPU mode the reference left as a TODO (H.cu:790).
+ */
+int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps);
+
+/*
  * Time `repeats` back-to-back searches with HIP events on the launch stream
  * (inputs resident, no copies inside the window).  Returns total milliseconds
  * in *total_ms and the dominant SA kernel's summed device time in *kernel_ms.

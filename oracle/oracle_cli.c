@@ -78,13 +78,14 @@ int main(int argc, char *argv[])
 {
     char dbfile[SAT_MAX_LINE_LEN] = "";
     char buf[SAT_MAX_LINE_LEN];
+    int gpu_row_format = 0;   /* -G: large-class rows as the reference GPU path prints them (cudaSaTabsearch.cu:1261) */
     int querydbmode = 0, maxstart = 128, philox = 0, small_limit = SAT_MAXDIM_SMALL;
     unsigned long long seed = 1234;
     int ltype = 0, lorder = 0, lsoln = 0;
     char cltype, clorder, clsoln;
     int c;
 
-    while ((c = getopt(argc, argv, "cq:r:ps:m:t")) != -1) {
+    while ((c = getopt(argc, argv, "cq:r:ps:m:tG")) != -1) {
         switch (c) {
         case 'c': break; /* always host */
         case 'q': querydbmode = 1; strncpy(dbfile, optarg, sizeof(dbfile) - 1); break;
@@ -92,6 +93,7 @@ int main(int argc, char *argv[])
         case 'p': philox = 1; break;
         case 's': seed = strtoull(optarg, NULL, 0); break;
         case 't': sa_oracle_trace = 1; break;
+        case 'G': gpu_row_format = 1; break;
         case 'm': small_limit = atoi(optarg); break; /* 2013 snapshot: MAXDIM_GPU = 32 */
         default:
             fprintf(stderr, "Usage: %s [-c] [-q dbfile] [-r restarts] [-p] [-s seed] [-m small_class_limit]\n", argv[0]);
@@ -235,8 +237,8 @@ int main(int argc, char *argv[])
                 double norm2score = sat_norm2(scores[d], q.n, cl->orders[d]);
                 double zscore = sat_z_gumbel_trunc(norm2score);
                 double pvalue = sat_pv_gumbel(zscore);
-                printf("%-8s %d %g %g %g\n", sat_set_name(&db, cl->set_index[d]),
-                       scores[d], norm2score, zscore, pvalue);
+                printf(gpu_row_format && k == 1 ? "%-8s %d %g %g  %g\n" : "%-8s %d %g %g %g\n",
+                       sat_set_name(&db, cl->set_index[d]), scores[d], norm2score, zscore, pvalue);
                 if (lsoln)
                     for (int i = 0; i < q.n; i++)
                         if (ssemaps[(size_t)d * SA_MAXDIM + i] >= 0)
