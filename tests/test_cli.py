@@ -71,6 +71,7 @@ def test_gpu_mode_query_list_and_large_class(tmp_path):
     every query's small-class block, with the reference GPU path's row format."""
     db = sat.synth.make_db(60, 70, 111, sort=False, seed=11)
     assert (db.orders > 96).sum() > 3 and (db.orders <= 96).sum() > 3
+    db.names = ["m%06d" % i for i in range(len(db))]        # -q cuts SIDs to 7 characters
     sat.synth.write_ascii(db, tmp_path / "mix.ascii")
     sids = (db.names[5] + "\n" + db.names[int(np.argmax(db.orders > 96))].upper() + "\n").encode()
     a = run(CLI, str(tmp_path), ["-r", "64", "-q", "mix.ascii"], stdin_bytes=sids)
