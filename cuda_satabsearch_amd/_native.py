@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-DEVICE_LIB = os.path.join(PKG, "libsatabsearch.so")
+# SAT_DEVICE_LIB lets kernel experiments (scripts/exp/) load an alternative build of the same ABI
+DEVICE_LIB = os.environ.get("SAT_DEVICE_LIB") or os.path.join(PKG, "libsatabsearch.so")
 HOST_LIB = os.path.join(PKG, "libsathost.so")
 
 MAXDIM = 111

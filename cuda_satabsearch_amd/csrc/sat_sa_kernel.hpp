@@ -89,6 +89,12 @@ template <int W> __device__ __forceinline__ Bits<W> bits_zero()
 template <int W> __device__ __forceinline__ Bits<W> bits_below(int pos)
 {
     Bits<W> b;
+    if constexpr (W == 1) {
+        // one word: ~(~0 << pos) for 0 < pos < 32, with the two saturating ends
+        uint32_t m = ~(0xFFFFFFFFu << (pos & 31));
+        b.w[0] = pos <= 0 ? 0u : (pos >= 32 ? 0xFFFFFFFFu : m);
+        return b;
+    }
 #pragma unroll
     for (int i = 0; i < W; i++) {
         int rel = pos - 32 * i;
@@ -192,6 +198,11 @@ __device__ __forceinline__ uint32_t pair_term(uint2 q, uint2 d)
 // key = seed_q, counter = (block, 0, subsequence lo, subsequence hi).
 __device__ __forceinline__ uint4 philox_block(uint64_t seed_q, uint64_t subsequence, uint32_t block)
 {
+#ifdef SAT_ABL_NO_PHILOX   // timing-only ablation (scripts/exp): a 3-op hash instead of 10 Philox rounds
+    uint32_t h = (uint32_t)(subsequence >> 32) * 0x9E3779B9u + block * 0x85EBCA6Bu + (uint32_t)subsequence;
+    h ^= h >> 15;
+    return uint4{ h * 0x2C1B3C6Du, h * 0x297A2D39u, (h ^ 0x5bd1e995u) * 0x7FEB352Du, h };
+#endif
     rocrand_state_philox4x32_10 st;
     rocrand_init(seed_q, subsequence, 4ull * block, &st);
     return rocrand4(&st);
@@ -294,7 +305,8 @@ sat_sa_kernel(const SatKernelArgs a)
     uint8_t *smap_b = reinterpret_cast<uint8_t *>(smap);
     uint8_t *bmap_b = reinterpret_cast<uint8_t *>(bmap);
     // byte k of this lane's map lives at ((k>>2)*T + tid)*4 + (k&3)
-    auto map_byte_addr = [&](int k) -> int { return (((k >> 2) * T + tid) << 2) + (k & 3); };
+    const int T4 = T << 2, tid4 = tid << 2;
+    auto map_byte_addr = [&](int k) -> int { return __mul24(k >> 2, T4) + tid4 + (k & 3); };
 
     const uint64_t subseq_lo = (uint64_t)a.ordinal[e];
     int best = SAT_K_NO_SCORE;
@@ -345,7 +357,7 @@ sat_sa_kernel(const SatKernelArgs a)
         int score = 0;
         for (int i = 0; i < n1 - 1; i++) {
             const int j = smap_b[map_byte_addr(i)];
-            const uint2 *drow = Dc + j * n2p;
+            const uint2 *drow = Dc + __mul24(j, n2p);
             for (int kw = (i + 1) >> 2; kw < n1w; kw++) {
                 const uint32_t word = smap[kw * T + tid];
 #pragma unroll
@@ -408,9 +420,12 @@ sat_sa_kernel(const SatKernelArgs a)
 
             // score change (deltasd, K.cu:502-535)
             const uint2 *qcol = Qc + ssei;
-            const uint2 *orow = Dc + oldj * n2p;
-            const uint2 *nrow = Dc + newj * n2p;
+            const uint2 *orow = Dc + __mul24(oldj, n2p);
+            const uint2 *nrow = Dc + __mul24(newj, n2p);
             uint32_t sum_new = 0, sum_old = 0;
+#ifdef SAT_EXP_UNROLL2
+#pragma unroll 2
+#endif
             for (int kw = 0; kw < n1w; kw++) {
                 const uint32_t word = smap[kw * T + tid];
 #pragma unroll
@@ -418,8 +433,21 @@ sat_sa_kernel(const SatKernelArgs a)
                     const int k = kw * 4 + s;
                     const int l = (word >> (8 * s)) & 0xFF;
                     const uint2 q = qcol[k * N1P];
+#if defined(SAT_ABL_NO_QREAD)     // timing-only ablation: no query-cell reads
+                    const uint2 q2 = uint2{ (uint32_t)k, (uint32_t)ssei };
+                    sum_new += pair_term(q2, nrow[l]);
+                    sum_old += pair_term(q2, orow[l]);
+#elif defined(SAT_ABL_NO_PAIRMATH) // timing-only ablation: loads only, trivial math
+                    { uint2 a = nrow[l], b = orow[l]; sum_new += a.x ^ q.x; sum_old += b.y ^ q.y; }
+#elif defined(SAT_ABL_NO_DREAD)     // timing-only ablation: no db-cell LDS reads
+                    sum_new += pair_term(q, uint2{ (uint32_t)l, q.y });
+                    sum_old += pair_term(q, uint2{ (uint32_t)l + 1u, q.y });
+#elif defined(SAT_ABL_NO_KLOOP)   // timing-only ablation: no pair evaluation at all
+                    sum_new += (uint32_t)l;
+#else
                     sum_new += pair_term(q, nrow[l]);
                     sum_old += pair_term(q, orow[l]);
+#endif
                 }
             }
             const int delta = (int)sum_new - (int)sum_old;
