@@ -75,7 +75,8 @@ struct sat_ctx {
     // query
     int n1 = 0, n1p = 0;
     uint32_t query_ordinal = 0;
-    uint2 *d_qcells = nullptr;
+    float4 *d_qdist = nullptr;              // [n1p/4][n1p] distances of 4 consecutive query SSEs
+    uint32_t *d_qcode = nullptr;            // [n1p/4][n1p] their code bytes
     uint8_t *d_qtypes = nullptr;
 
     // Metropolis table
@@ -186,7 +187,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     a.tab_tri = ctx->d_tab;
     a.dist_tri = ctx->d_dist;
     a.ordinal = ctx->d_ordinal;
-    a.qcells = ctx->d_qcells;
+    a.qdist = ctx->d_qdist;
+    a.qcode = ctx->d_qcode;
     a.qtypes = ctx->d_qtypes;
     a.n1 = ctx->n1;
     a.lorder = lorder ? 1 : 0;
@@ -289,7 +291,8 @@ void sat_ctx_destroy(sat_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_db(ctx);
-    dev_free(ctx->d_qcells);
+    dev_free(ctx->d_qdist);
+    dev_free(ctx->d_qcode);
     dev_free(ctx->d_qtypes);
     dev_free(ctx->d_ptab);
     dev_free(ctx->d_prow);
@@ -313,8 +316,17 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
             return fail(SAT_EINVAL, "entry %d: order %d outside 1..%d", e, n, SAT_MAXDIM);
         if (cell_off[e] < 0) return fail(SAT_EINVAL, "entry %d: negative cell offset", e);
         for (int i = 0; i < n; i++) {
-            uint8_t t = tab_tri[cell_off[e] + (int64_t)i * (i + 1) / 2 + i];
+            const int64_t rowbase = cell_off[e] + (int64_t)i * (i + 1) / 2;
+            uint8_t t = tab_tri[rowbase + i];
             if (t > 3) return fail(SAT_EINVAL, "entry %d: SSE %d has type code %u (0..3 expected)", e, i, t);
+            for (int j = 0; j < i; j++) {
+                // the packed pair arithmetic needs nibbles 0..7 (the reader produces 0..4)
+                if (tab_tri[rowbase + j] & 0x88)
+                    return fail(SAT_EINVAL, "entry %d: tableau code 0x%02x at (%d,%d) has a nibble above 7", e, tab_tri[rowbase + j], i, j);
+                float d = dist_tri[rowbase + j];
+                if (std::isfinite(d) && std::fabs(d) >= 1.0e29f)
+                    return fail(SAT_EINVAL, "entry %d: distance %g at (%d,%d) out of range", e, d, i, j);
+            }
         }
         int64_t end = cell_off[e] + (int64_t)n * (n + 1) / 2;
         if (end > cells_end) cells_end = end;
@@ -406,30 +418,46 @@ int sat_query_set(sat_ctx *ctx, int n1, const uint8_t *qtab, const float *qdmat,
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const int n1p = n1 <= 16 ? 16 : (n1 <= 32 ? 32 : (n1 <= 64 ? 64 : 112));
 
-    // transposed cells: row k, column i holds (dmat1[i][k], mask of tab1[i][k]);
-    // diagonal and padding get a NaN distance so they never score
-    std::vector<uint2> cells((size_t)n1p * n1p);
-    for (int k = 0; k < n1p; k++)
+    // grouped, transposed query: group kw, column i holds dmat1[i][4kw..4kw+3] and the four code
+    // bytes tab1[i][4kw..4kw+3]; diagonal, padding and non-finite distances get the sentinel
+    // so they never score (the reference excludes k == i, K.cu:524, and NaN never passes <= 4)
+    const int groups = n1p / 4;
+    std::vector<float4> qdist((size_t)groups * n1p);
+    std::vector<uint32_t> qcode((size_t)groups * n1p);
+    for (int kw = 0; kw < groups; kw++)
         for (int i = 0; i < n1p; i++) {
-            uint2 c;
-            c.x = 0x7FC00000u;
-            c.y = 0u;
-            if (k < n1 && i < n1 && k != i) {
-                float d = qdmat[(size_t)i * pitch + k];
-                memcpy(&c.x, &d, 4);
-                uint32_t code = qtab[(size_t)i * pitch + k];
-                c.y = (1u << ((code >> 4) & 15u)) | (1u << (16u + (code & 15u)));
+            float d[4];
+            uint32_t codes = 0;
+            for (int sidx = 0; sidx < 4; sidx++) {
+                const int k = 4 * kw + sidx;
+                d[sidx] = SAT_K_QSENT;
+                if (k < n1 && i < n1 && k != i) {
+                    const float v = qdmat[(size_t)i * pitch + k];
+                    const uint32_t code = qtab[(size_t)i * pitch + k];
+                    if (code & 0x88)
+                        return fail(SAT_EINVAL, "query tableau code 0x%02x at (%d,%d) has a nibble above 7", code, i, k);
+                    if (std::isfinite(v)) {
+                        if (std::fabs(v) >= 1.0e29f)
+                            return fail(SAT_EINVAL, "query distance %g at (%d,%d) out of range", v, i, k);
+                        d[sidx] = v;
+                    }
+                    codes |= code << (8 * sidx);
+                }
             }
-            cells[(size_t)k * n1p + i] = c;
+            qdist[(size_t)kw * n1p + i] = float4{ d[0], d[1], d[2], d[3] };
+            qcode[(size_t)kw * n1p + i] = codes;
         }
     std::vector<uint8_t> types((size_t)n1p, 0);
     memcpy(types.data(), qssetypes, (size_t)n1);
 
-    dev_free(ctx->d_qcells);
+    dev_free(ctx->d_qdist);
+    dev_free(ctx->d_qcode);
     dev_free(ctx->d_qtypes);
-    HIP_TRY(hipMalloc(&ctx->d_qcells, cells.size() * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&ctx->d_qdist, qdist.size() * sizeof(float4)));
+    HIP_TRY(hipMalloc(&ctx->d_qcode, qcode.size() * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&ctx->d_qtypes, types.size()));
-    HIP_TRY(hipMemcpy(ctx->d_qcells, cells.data(), cells.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_qdist, qdist.data(), qdist.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_qcode, qcode.data(), qcode.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_qtypes, types.data(), types.size(), hipMemcpyHostToDevice));
     ctx->n1 = n1;
     ctx->n1p = n1p;

@@ -6,25 +6,39 @@
 // 64-wide wavefronts and the 160 KB LDS; what it computes follows the reference
 // kernel body K.cu:924-1233 (K.cu = nvcc_src_current/cudaSaTabsearch_kernel.cu).
 //
-// Data layout in LDS (per workgroup)
-//   Dc   (n2+1) x (n2+1) 8-byte cells {f32 distance, u32 code mask} of the db entry,
-//        expanded from the packed lower triangle in HBM.  Row n2 and column n2 are a
-//        "null" SSE whose distance is NaN: an unmatched query SSE is represented as
-//        matched to the null SSE, so |d1 - NaN| <= 4 is false and the pair scores 0
-//        without any branch or predicate in the hot loop.
-//   Qc   query cells, TRANSPOSED: Qc[k*N1P + i] = {dmat1[i][k], mask(tab1[i][k])}.
-//        The hot loop reads column i = the moved SSE (different per lane) of row k
-//        (same for all lanes): consecutive i are consecutive 8-byte cells, so the
-//        64 lanes of a ds_read_b64 hit distinct banks or broadcast - conflict free.
-//        The diagonal distance is NaN, which removes the k == i term (K.cu:524,530).
-//   smap per-lane SSE map, one byte per query SSE, stored word-interleaved
+// Data layout
+//   Dc   (LDS) (n2+1) x (n2+1) 8-byte cells {f32 distance, u32 code byte} of the db
+//        entry, expanded from the packed lower triangle in HBM.  Row n2 and column n2
+//        are a "null" SSE whose distance is the sentinel -1e30: an unmatched query SSE
+//        is represented as matched to the null SSE, so |d1 - d2| <= 4 is false and the
+//        pair scores 0 without any branch or predicate in the hot loop (the reference
+//        tests l >= 0, old_j >= 0, k != sse_i per pair, K.cu:521-531).
+//   Q    query, grouped by 4 consecutive query SSEs k (one "word" of the map) and
+//        TRANSPOSED: qdist[kw*N1P + i] = float4 of dmat1[i][4kw..4kw+3],
+//        qcode[kw*N1P + i] = the four code bytes tab1[i][4kw..4kw+3] packed in a dword.
+//        The hot loop reads column i = the moved SSE (different per lane) of group kw
+//        (same for all lanes): 16-byte and 4-byte loads from consecutive addresses.
+//        Diagonal and padding distances are the sentinel +1e30, which removes the k == i
+//        term (K.cu:524,530).  Read through L1/L2 (32+-SSE queries) or staged in LDS.
+//   smap (LDS) per-lane SSE map, one byte per query SSE, stored word-interleaved
 //        smap[w*T + tid]: word w of every lane is contiguous, so the uniform-k loop
 //        reads it conflict free and a lane's random byte access always lands in bank
 //        (tid mod 32) - also conflict free.
 //   bmap same layout, best map so far (LSOLN only).
-//   A code byte (hi nibble, lo nibble; parsetableaux.c:13-33) becomes the mask
-//        (1 << hi) | (1 << (16 + lo)); popcount(maskA & maskB) = number of equal
-//        nibbles, from which tscord's 2 / 1 / -2 (K.cu:306-332) is a 4-entry lookup.
+//
+// Pair scores, four at a time (quad_terms): gfx950 issues and/or/xor/add/sub/lshr/
+// bitop3/f32 add at one wave64 op per ~2.4 clk and everything else (cmp, cndmask, bcnt,
+// perm, shifts left, SDWA, mad) at ~4.2 clk (profiles/r01_gfx950_valu_opcode_cost.txt), so
+// the four pairs of a map word are evaluated with packed byte arithmetic:
+//   * code bytes are (hi << 4) | lo with hi, lo <= 7 (parsetableaux.c:13-33 uses 0..4):
+//     bits 3 and 7 are free guard bits;  X = codes(db, 4 bytes) ^ codes(query, 4 bytes);
+//     (X + 0x77777777) & 0x88888888 has bit 3 / bit 7 of byte s set iff the low / high
+//     nibble of pair s differs;
+//   * distance test: t = 4 - |d1 - d2| is >= 0 exactly when |d1 - d2| <= 4 in f32 (the
+//     reference's test K.cu:432, 524, 530); the four sign bytes are gathered by v_perm;
+//   * the 3-bit index (lo differs, hi differs, too far) of every pair selects one of
+//     {2, 1, 1, -2, 0, 0, 0, 0} = tscord (K.cu:306-332) gated by distance, all four with
+//     ONE v_perm_b32, and v_dot4_i32_i8 adds the four signed bytes to the running sum.
 //
 // Free-SSE bookkeeping uses bit masks instead of the reference's int revmap[] and
 // 111-int candidate list (K.cu:677-714): occ = occupied db SSEs, mapped = matched
@@ -49,6 +63,8 @@
 #define SAT_K_STEP_BLOCK0 32          // Philox block of SA step 0 (oracle/sa_oracle.h)
 #define SAT_K_EPS 1.1e-7              // K.cu:67
 #define SAT_K_NO_SCORE (-99999)       // K.cu:1009
+#define SAT_K_QSENT 1.0e30f            // query-side "never within 4 A" distance
+#define SAT_K_DSENT (-1.0e30f)         // db-side sentinel (null SSE, non-finite input)
 
 struct SatKernelArgs {
     // database shard (HBM)
@@ -59,7 +75,8 @@ struct SatKernelArgs {
     const uint32_t *ordinal;      // [N] db file-order ordinal (stream key)
     const int32_t  *entry_list;   // entries handled by this launch (one per workgroup)
     // query
-    const uint2    *qcells;       // [N1P][N1P] transposed cells {dist bits, mask}
+    const float4   *qdist;        // [N1P/4][N1P] distances of 4 consecutive query SSEs (transposed)
+    const uint32_t *qcode;        // [N1P/4][N1P] their 4 code bytes
     const uint8_t  *qtypes;       // [N1P]
     int32_t         n1;
     // options
@@ -170,27 +187,34 @@ template <int W> __device__ __forceinline__ int bits_select(const Bits<W> &b, in
     return pos;
 }
 
-// ---------------------------------------------------------------- cells and scores
-__device__ __forceinline__ uint32_t code_mask(uint32_t code)
+// ---------------------------------------------------------------- pair scores
+// Sum of the four pair scores of one map word: query SSEs 4kw..4kw+3 against the db SSEs
+// in `word` (one byte each), all on db row `row` (the image of the moved / anchor SSE).
+//   qd, qc   the query group's distances and code bytes for this lane's column
+//   force    0x04 in byte s forces pair s to score 0 (used by the full score for k <= i)
+// Returns acc + sum.  See the file header for the arithmetic.
+__device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const uint2 *row,
+                                          const uint32_t word, const uint32_t force, const int acc)
 {
-    return (1u << ((code >> 4) & 15u)) | (1u << (16u + (code & 15u)));
-}
-
-// tscord (K.cu:306-332) gated by the SSE-distance test (K.cu:432, 524, 530), biased by
-// +2 so that it is an unsigned byte: returns 2 when the distances differ by more than
-// 4 A (or either is the NaN of a null SSE / the query diagonal), else 4 / 3 / 0 for
-// two / one / no equal nibbles (= 2 + {2, 1, -2}).  Both sides of a move evaluate the
-// same number of terms, so the bias cancels in new - old; the full score subtracts it.
-// One v_perm_b32 does the 4-entry table lookup: selector byte 0 = 0..3 picks a byte of
-// the table, selector bytes 1..3 = 0x0C yield zero.
-#define SAT_K_TERM_BIAS 2
-__device__ __forceinline__ uint32_t pair_term(uint2 q, uint2 d)
-{
-    float diff = __uint_as_float(q.x) - __uint_as_float(d.x);
-    bool ok = fabsf(diff) <= 4.0f;
-    uint32_t sel = (uint32_t)__popc(q.y & d.y) + 0x0C0C0C01u;
-    sel = ok ? sel : 0x0C0C0C00u;
-    return __builtin_amdgcn_perm(0u, 0x04030002u, sel);
+    const uint2 d0 = row[word & 0xFFu];
+    const uint2 d1 = row[(word >> 8) & 0xFFu];
+    const uint2 d2 = row[(word >> 16) & 0xFFu];
+    const uint2 d3 = row[word >> 24];
+    // sign bit of t = "distances differ by more than 4 A"
+    const float t0 = 4.0f - fabsf(qd.x - __uint_as_float(d0.x));
+    const float t1 = 4.0f - fabsf(qd.y - __uint_as_float(d1.x));
+    const float t2 = 4.0f - fabsf(qd.z - __uint_as_float(d2.x));
+    const float t3 = 4.0f - fabsf(qd.w - __uint_as_float(d3.x));
+    // v_perm_b32(S0, S1, sel): selector 0-3 = byte of S1, 4-7 = byte of S0, 0x0C = zero
+    const uint32_t far = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x0C0C0703u) |
+                         __builtin_amdgcn_perm(__float_as_uint(t3), __float_as_uint(t2), 0x07030C0Cu);
+    const uint32_t x = __builtin_amdgcn_perm(d1.y, d0.y, 0x0C0C0400u) ^
+                       __builtin_amdgcn_perm(d3.y, d2.y, 0x04000C0Cu) ^ qc;
+    const uint32_t z = (x + 0x77777777u) & 0x88888888u;             // bit 3: low nibbles differ, bit 7: high
+    uint32_t sel = ((z >> 3) | (z >> 6)) & 0x03030303u;
+    sel |= ((far >> 5) & 0x04040404u) | force;
+    const uint32_t terms = __builtin_amdgcn_perm(0u, 0xFE010102u, sel);   // {2, 1, 1, -2 | 0, 0, 0, 0}
+    return __builtin_amdgcn_sdot4((int)terms, 0x01010101, acc, false);
 }
 
 // ---------------------------------------------------------------- random streams
@@ -224,7 +248,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int threads
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
     dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
     size_t bytes = dcells * 8;
-    if (q_in_lds) bytes += n1w * 4 * (size_t)n1p * 8;
+    if (q_in_lds) bytes += n1w * (size_t)n1p * 20;            // float4 + code dword per (group, column)
     bytes += n1w * threads * 4 * (lsoln ? 2 : 1);
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
@@ -258,13 +282,15 @@ sat_sa_kernel(const SatKernelArgs a)
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
     dcells = (dcells + 1) & ~(size_t)1;
     uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);
-    uint2 *QcL = Dc + dcells;
-    uint32_t *smap = reinterpret_cast<uint32_t *>(QcL + (QLDS ? (size_t)n1w * 4 * N1P : 0));
+    float4 *qdistL = reinterpret_cast<float4 *>(Dc + dcells);
+    uint32_t *qcodeL = reinterpret_cast<uint32_t *>(qdistL + (QLDS ? (size_t)n1w * N1P : 0));
+    uint32_t *smap = qcodeL + (QLDS ? (size_t)n1w * N1P : 0);
     uint32_t *bmap = smap + (size_t)n1w * T;
     uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * T : 0);
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
     unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
-    const uint2 *Qc = QLDS ? QcL : a.qcells;
+    const float4 *qdist = QLDS ? qdistL : a.qdist;
+    const uint32_t *qcode = QLDS ? qcodeL : a.qcode;
 
     // ---- stage the db entry: packed lower triangle (HBM) -> full cell matrix (LDS)
     {
@@ -278,10 +304,12 @@ sat_sa_kernel(const SatKernelArgs a)
             if (j < n2 && l < n2) {
                 int hi = j > l ? j : l, lo = j > l ? l : j;
                 int t = hi * (hi + 1) / 2 + lo;
-                cell.x = __float_as_uint(dd[t]);
-                cell.y = code_mask(tt[t]);
+                const float v = dd[t];
+                // NaN / inf never pass the reference's |d1 - d2| <= 4 either: same as the sentinel
+                cell.x = __float_as_uint(fabsf(v) <= 3.0e38f ? v : SAT_K_DSENT);
+                cell.y = tt[t];
             } else {
-                cell.x = 0x7FC00000u;   // NaN: the null SSE never passes the distance test
+                cell.x = __float_as_uint(SAT_K_DSENT);   // the null SSE never passes the distance test
                 cell.y = 0u;
             }
             Dc[c] = cell;
@@ -289,10 +317,11 @@ sat_sa_kernel(const SatKernelArgs a)
         if (tid < 16) tmask[tid] = 0u;
         for (int i = tid; i < N1P; i += T) qtypes[i] = a.qtypes[i];
         if (QLDS) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(a.qcells);
-            uint4 *dst = reinterpret_cast<uint4 *>(QcL);
-            const int vecs = n1w * 4 * N1P / 2;
-            for (int c = tid; c < vecs; c += T) dst[c] = src[c];
+            const int groups = n1w * N1P;
+            for (int c = tid; c < groups; c += T) {
+                qdistL[c] = a.qdist[c];
+                qcodeL[c] = a.qcode[c];
+            }
         }
     }
     __syncthreads();
@@ -353,21 +382,16 @@ sat_sa_kernel(const SatKernelArgs a)
             }
         }
 
-        // ---- full score of the initial map (tmscord, K.cu:396-440)
+        // ---- full score of the initial map (tmscord, K.cu:396-440): pairs i < k
         int score = 0;
         for (int i = 0; i < n1 - 1; i++) {
             const int j = smap_b[map_byte_addr(i)];
             const uint2 *drow = Dc + __mul24(j, n2p);
             for (int kw = (i + 1) >> 2; kw < n1w; kw++) {
-                const uint32_t word = smap[kw * T + tid];
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int k = kw * 4 + s;
-                    if (k > i) {                                  // wave-uniform
-                        const int l = (word >> (8 * s)) & 0xFF;
-                        score += (int)pair_term(Qc[k * N1P + i], drow[l]) - SAT_K_TERM_BIAS;
-                    }
-                }
+                // pairs with k <= i inside the first word are switched off (wave-uniform mask)
+                const int below = i + 1 - 4 * kw;
+                const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
+                score = quad_terms(qdist[kw * N1P + i], qcode[kw * N1P + i], drow, smap[kw * T + tid], force, score);
             }
         }
         if (score > best) {
@@ -419,38 +443,17 @@ sat_sa_kernel(const SatKernelArgs a)
             }
 
             // score change (deltasd, K.cu:502-535)
-            const uint2 *qcol = Qc + ssei;
             const uint2 *orow = Dc + __mul24(oldj, n2p);
             const uint2 *nrow = Dc + __mul24(newj, n2p);
-            uint32_t sum_new = 0, sum_old = 0;
-#ifdef SAT_EXP_UNROLL2
-#pragma unroll 2
-#endif
+            int sum_new = 0, sum_old = 0;
             for (int kw = 0; kw < n1w; kw++) {
                 const uint32_t word = smap[kw * T + tid];
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int k = kw * 4 + s;
-                    const int l = (word >> (8 * s)) & 0xFF;
-                    const uint2 q = qcol[k * N1P];
-#if defined(SAT_ABL_NO_QREAD)     // timing-only ablation: no query-cell reads
-                    const uint2 q2 = uint2{ (uint32_t)k, (uint32_t)ssei };
-                    sum_new += pair_term(q2, nrow[l]);
-                    sum_old += pair_term(q2, orow[l]);
-#elif defined(SAT_ABL_NO_PAIRMATH) // timing-only ablation: loads only, trivial math
-                    { uint2 a = nrow[l], b = orow[l]; sum_new += a.x ^ q.x; sum_old += b.y ^ q.y; }
-#elif defined(SAT_ABL_NO_DREAD)     // timing-only ablation: no db-cell LDS reads
-                    sum_new += pair_term(q, uint2{ (uint32_t)l, q.y });
-                    sum_old += pair_term(q, uint2{ (uint32_t)l + 1u, q.y });
-#elif defined(SAT_ABL_NO_KLOOP)   // timing-only ablation: no pair evaluation at all
-                    sum_new += (uint32_t)l;
-#else
-                    sum_new += pair_term(q, nrow[l]);
-                    sum_old += pair_term(q, orow[l]);
-#endif
-                }
+                const float4 qd = qdist[kw * N1P + ssei];
+                const uint32_t qc = qcode[kw * N1P + ssei];
+                sum_new = quad_terms(qd, qc, nrow, word, 0u, sum_new);
+                sum_old = quad_terms(qd, qc, orow, word, 0u, sum_old);
             }
-            const int delta = (int)sum_new - (int)sum_old;
+            const int delta = sum_new - sum_old;
             const int newscore = score + delta;
 
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
