@@ -159,6 +159,14 @@ def main():
         kavg_ms = float(np.mean(kernel_ms))
         abytes = algorithmic_bytes_per_scoring(ORDER) * n_local
         achieved = abytes / (kavg_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the rocprofv3 PMC passes of this same command (profiles/)
+        traffic = None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "bench_traffic.json")))
+            if t.get("entries_per_launch") == n_local:
+                traffic = t["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "db-structure scorings/sec (query x db pairs/sec) at r=128",
             "value": value, "unit": "db-structure scorings/sec", "n_gpus": world,
@@ -173,8 +181,8 @@ def main():
                        "parallelism": "db-shard x%d" % world},
             "sa_steps_per_sec": value * MAXSTART * MAXITER,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sat_sa_kernel<32,1,true>", "kernel_ms_avg": kavg_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "sat_sa_kernel<32,1,false>", "kernel_ms_avg": kavg_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "nominal bound only: 2648 B per scoring against 12 800 dependent SA steps; "
                                  "the kernel is VALU/LDS-issue bound (DESIGN.md section 4)"},
