@@ -283,21 +283,52 @@ int main(int argc, char *argv[])
         if (lsoln) large_maps = (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)cls_count[1] * num_queries);
         if (!large_scores || (lsoln && !large_maps)) { fprintf(stderr, "malloc failed\n"); exit(1); }
     }
-    uint8_t *qtab = (uint8_t *)calloc(SAT_MAXDIM * SAT_MAXDIM, 1);
-    float *qdmat = (float *)calloc(SAT_MAXDIM * SAT_MAXDIM, sizeof(float));
-    uint8_t qtypes[SAT_MAXDIM];
+
+    /* Queries go to the GPUs in batches: one set of launches scores a whole batch (grid =
+     * entries x queries), which is what fills the machine when the database is small and the
+     * query list long (-q).  The batch size is bounded by the host result buffers. */
+    int batch = 256;
+    {
+        const size_t per_query = (size_t)total * (lsoln ? (SAT_MAXDIM + 1) : 1) * sizeof(int32_t);
+        const size_t budget = (size_t)1 << 30;
+        if ((size_t)batch * per_query > budget) batch = (int)(budget / per_query);
+        if (batch < 1) batch = 1;
+        if (batch > num_queries) batch = num_queries;
+    }
+    free(scores);
+    free(ssemaps);
+    scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)total * batch);
+    ssemaps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)total * batch) : NULL;
+    int max_shard = 0;
+    for (int g = 0; g < ngpu; g++)
+        if (shard_begin[g + 1] - shard_begin[g] > max_shard) max_shard = shard_begin[g + 1] - shard_begin[g];
+    int32_t *shard_scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_shard * batch);
+    int32_t *shard_maps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)max_shard * batch) : NULL;
+    uint8_t *qtabs = (uint8_t *)calloc((size_t)batch * SAT_MAXDIM * SAT_MAXDIM, 1);
+    float *qdmats = (float *)calloc((size_t)batch * SAT_MAXDIM * SAT_MAXDIM, sizeof(float));
+    uint8_t *qtypes = (uint8_t *)calloc((size_t)batch * SAT_MAXDIM, 1);
+    int32_t *n1s = (int32_t *)malloc(sizeof(int32_t) * (size_t)batch);
+    if (!scores || (lsoln && !ssemaps) || !shard_scores || (lsoln && !shard_maps) || !qtabs || !qdmats || !qtypes || !n1s) {
+        fprintf(stderr, "malloc failed\n");
+        exit(1);
+    }
     int exit_status = 0;
 
-    for (int qi = 0; qi < num_queries; qi++) {
-        const int qs = qindex[qi], n1 = qsrc->order[qs];
-        sat_set_expand(qsrc, qs, SAT_MAXDIM, qtab, qdmat);
-        for (int i = 0; i < n1; i++) qtypes[i] = qtab[i * SAT_MAXDIM + i];
-        print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
-        fprintf(stderr, "Executing simulated annealing tableaux match kernel on GPU for qid %s...\n",
-                sat_set_name(qsrc, qs));
+    for (int q0 = 0; q0 < num_queries; q0 += batch) {
+        const int nqb = num_queries - q0 < batch ? num_queries - q0 : batch;
+        for (int b = 0; b < nqb; b++) {
+            const int qs = qindex[q0 + b];
+            n1s[b] = qsrc->order[qs];
+            sat_set_expand(qsrc, qs, SAT_MAXDIM, qtabs + (size_t)b * SAT_MAXDIM * SAT_MAXDIM,
+                           qdmats + (size_t)b * SAT_MAXDIM * SAT_MAXDIM);
+            for (int i = 0; i < n1s[b]; i++)
+                qtypes[(size_t)b * SAT_MAXDIM + i] = qtabs[(size_t)b * SAT_MAXDIM * SAT_MAXDIM + i * SAT_MAXDIM + i];
+        }
+        fprintf(stderr, "Executing simulated annealing tableaux match kernel on GPU for %d quer%s (from %s)...\n",
+                nqb, nqb == 1 ? "y" : "ies", sat_set_name(qsrc, qindex[q0]));
         double t1 = now_ms();
         for (int g = 0; g < ngpu; g++) {
-            if (sat_query_set(ctx[g], n1, qtab, qdmat, SAT_MAXDIM, qtypes, (uint32_t)qi) != SAT_OK ||
+            if (sat_queries_set(ctx[g], nqb, n1s, qtabs, qdmats, SAT_MAXDIM, qtypes, (uint32_t)q0) != SAT_OK ||
                 sat_search_async(ctx[g], lorder, lsoln, maxstart) != SAT_OK) {
                 fprintf(stderr, "kernel launch failed: %s\n", sat_last_error());
                 exit_status = 1;
@@ -305,28 +336,40 @@ int main(int argc, char *argv[])
             }
         }
         for (int g = 0; g < ngpu; g++) {
-            int b = shard_begin[g];
-            if (sat_results(ctx[g], lsoln, scores + b, ssemaps ? ssemaps + (size_t)b * SAT_MAXDIM : NULL) != SAT_OK) {
+            const int sb = shard_begin[g], sn = shard_begin[g + 1] - sb;
+            if (sat_results(ctx[g], lsoln, shard_scores, shard_maps) != SAT_OK) {
                 fprintf(stderr, "GPU %d search failed: %s\n", g, sat_last_error());
                 exit_status = 1;
                 goto bye;
+            }
+            for (int b = 0; b < nqb; b++) {          /* [query][shard entry] -> [query][db entry] */
+                memcpy(scores + (size_t)b * total + sb, shard_scores + (size_t)b * sn, sizeof(int32_t) * (size_t)sn);
+                if (lsoln)
+                    memcpy(ssemaps + ((size_t)b * total + sb) * SAT_MAXDIM, shard_maps + (size_t)b * sn * SAT_MAXDIM,
+                           sizeof(int32_t) * SAT_MAXDIM * (size_t)sn);
             }
         }
         double ms = now_ms() - t1;
         fprintf(stderr, "GPU execution time %f ms\n", ms);
         fprintf(stderr, "%f million iterations/sec\n",
-                ((double)total * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
-        for (int d = 0; d < cls_count[0]; d++) {
-            int s = cls_index[0][d];
-            print_row(sat_set_name(&db, s), scores[s], n1, db.order[s],
-                      ssemaps ? ssemaps + (size_t)s * SAT_MAXDIM : NULL, lsoln, 0);
-        }
-        for (int d = 0; d < cls_count[1]; d++) {
-            int s = cls_index[1][d];
-            large_scores[(size_t)qi * cls_count[1] + d] = scores[s];
-            if (lsoln)
-                memcpy(large_maps + ((size_t)qi * cls_count[1] + d) * SAT_MAXDIM,
-                       ssemaps + (size_t)s * SAT_MAXDIM, sizeof(int32_t) * SAT_MAXDIM);
+                ((double)total * nqb * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
+        for (int b = 0; b < nqb; b++) {
+            const int qi = q0 + b, qs = qindex[qi], n1 = n1s[b];
+            const int32_t *qscores = scores + (size_t)b * total;
+            const int32_t *qmaps = ssemaps ? ssemaps + (size_t)b * total * SAT_MAXDIM : NULL;
+            print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
+            for (int d = 0; d < cls_count[0]; d++) {
+                int s = cls_index[0][d];
+                print_row(sat_set_name(&db, s), qscores[s], n1, db.order[s],
+                          qmaps ? qmaps + (size_t)s * SAT_MAXDIM : NULL, lsoln, 0);
+            }
+            for (int d = 0; d < cls_count[1]; d++) {
+                int s = cls_index[1][d];
+                large_scores[(size_t)qi * cls_count[1] + d] = qscores[s];
+                if (lsoln)
+                    memcpy(large_maps + ((size_t)qi * cls_count[1] + d) * SAT_MAXDIM,
+                           qmaps + (size_t)s * SAT_MAXDIM, sizeof(int32_t) * SAT_MAXDIM);
+            }
         }
     }
     if (cls_count[1] > 0)

@@ -72,19 +72,23 @@ struct sat_ctx {
     int bucket_n2max[kNumBuckets] = { 0 };
     std::vector<int32_t> h_orders;
 
-    // query
-    int n1 = 0, n1p = 0;
-    uint32_t query_ordinal = 0;
-    float4 *d_qdist = nullptr;              // [n1p/4][n1p] distances of 4 consecutive query SSEs
-    uint32_t *d_qcode = nullptr;            // [n1p/4][n1p] their code bytes
-    uint8_t *d_qtypes = nullptr;
+    // queries (a batch; one query is a batch of 1), input order
+    struct QueryInfo { int n1, n1p; uint32_t ordinal; size_t blob_off; size_t ssemap_off; };
+    std::vector<QueryInfo> queries;
+    uint8_t *d_qblob = nullptr;             // per query: qdist | qcode | qtypes
+    SatQuery *d_qdesc = nullptr;            // descriptors grouped by size class
+    int class_begin[5] = { 0, 0, 0, 0, 0 };  // classes: n1p = 16, 32, 64, 112
+    int class_n1max[4] = { 0, 0, 0, 0 };
+    bool desc_dirty = true;
+    bool desc_lsoln = false;
 
     // Metropolis table
     float *d_ptab = nullptr;
     int32_t *d_prow = nullptr;
 
-    // results
+    // results: scores [nq][N]; ssemaps: query q's [N][n1_q] block at queries[q].ssemap_off
     int32_t *d_scores = nullptr;
+    size_t scores_cap = 0;
     int8_t *d_ssemaps = nullptr;
     size_t ssemaps_cap = 0;
 };
@@ -132,7 +136,9 @@ void free_db(sat_ctx *ctx)
     dev_free(ctx->d_lists);
     dev_free(ctx->d_scores);
     dev_free(ctx->d_ssemaps);
+    ctx->scores_cap = 0;
     ctx->ssemaps_cap = 0;
+    ctx->desc_dirty = true;
     ctx->n_entries = 0;
     ctx->h_orders.clear();
 }
@@ -146,12 +152,11 @@ template <int N1P> kernel_fn pick_m2w(int m2w, bool qlds)
         if (m2w == 2) return sat_sa_kernel<N1P, 2, true>;
         return sat_sa_kernel<N1P, 4, true>;
     }
-    if constexpr (N1P >= 32) {
+    {
         if (m2w == 1) return sat_sa_kernel<N1P, 1, false>;
         if (m2w == 2) return sat_sa_kernel<N1P, 2, false>;
         return sat_sa_kernel<N1P, 4, false>;
     }
-    return nullptr;
 }
 
 kernel_fn pick_kernel(int n1p, int m2w, bool qlds)
@@ -164,22 +169,76 @@ kernel_fn pick_kernel(int n1p, int m2w, bool qlds)
     }
 }
 
-int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t stream)
-{
-    if (!ctx) return fail(SAT_EINVAL, "null context");
-    if (ctx->n_entries <= 0) return fail(SAT_ESTATE, "no database uploaded");
-    if (ctx->n1 <= 0) return fail(SAT_ESTATE, "no query set");
-    if (maxstart < 1) return fail(SAT_EINVAL, "maxstart must be >= 1 (got %d)", maxstart);
-    HIP_TRY(hipSetDevice(ctx->device));
+const int kClassN1P[4] = { 16, 32, 64, 112 };
 
+// (re)build the device query descriptors: pointers into the query blob and into the result
+// buffers, grouped by size class
+int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
+{
+    const size_t nq = ctx->queries.size();
+    const size_t need_scores = nq * (size_t)ctx->n_entries;
+    if (need_scores > ctx->scores_cap) {
+        dev_free(ctx->d_scores);
+        HIP_TRY(hipMalloc(&ctx->d_scores, need_scores * sizeof(int32_t)));
+        ctx->scores_cap = need_scores;
+        ctx->desc_dirty = true;
+    }
     if (lsoln) {
-        size_t need = (size_t)ctx->n_entries * ctx->n1;
+        size_t need = 0;
+        for (auto &q : ctx->queries) {
+            q.ssemap_off = need;
+            need += (size_t)ctx->n_entries * q.n1;
+        }
         if (need > ctx->ssemaps_cap) {
             dev_free(ctx->d_ssemaps);
             HIP_TRY(hipMalloc(&ctx->d_ssemaps, need));
             ctx->ssemaps_cap = need;
+            ctx->desc_dirty = true;
+        }
+        if (!ctx->desc_lsoln) ctx->desc_dirty = true;
+    }
+    if (!ctx->desc_dirty) return SAT_OK;
+
+    std::vector<SatQuery> desc;
+    desc.reserve(nq);
+    for (int c = 0; c < 4; c++) {
+        ctx->class_begin[c] = (int)desc.size();
+        ctx->class_n1max[c] = 0;
+        for (size_t qi = 0; qi < nq; qi++) {
+            const auto &q = ctx->queries[qi];
+            if (q.n1p != kClassN1P[c]) continue;
+            const size_t groups = (size_t)q.n1p / 4 * q.n1p;
+            SatQuery d;
+            d.qdist = reinterpret_cast<const float4 *>(ctx->d_qblob + q.blob_off);
+            d.qcode = reinterpret_cast<const uint32_t *>(ctx->d_qblob + q.blob_off + groups * 16);
+            d.qtypes = ctx->d_qblob + q.blob_off + groups * 20;
+            d.n1 = q.n1;
+            d.pad_ = 0;
+            d.seed_q = ctx->seed + ((uint64_t)q.ordinal << 32);
+            d.scores = ctx->d_scores + qi * (size_t)ctx->n_entries;
+            d.ssemaps = lsoln ? ctx->d_ssemaps + q.ssemap_off : nullptr;
+            desc.push_back(d);
+            if (q.n1 > ctx->class_n1max[c]) ctx->class_n1max[c] = q.n1;
         }
     }
+    ctx->class_begin[4] = (int)desc.size();
+    // ordered after earlier launches on the stream; the host vector dies at return, so wait
+    HIP_TRY(hipMemcpyAsync(ctx->d_qdesc, desc.data(), desc.size() * sizeof(SatQuery), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    ctx->desc_dirty = false;
+    ctx->desc_lsoln = lsoln;
+    return SAT_OK;
+}
+
+int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t stream)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (ctx->n_entries <= 0) return fail(SAT_ESTATE, "no database uploaded");
+    if (ctx->queries.empty()) return fail(SAT_ESTATE, "no query set");
+    if (maxstart < 1) return fail(SAT_EINVAL, "maxstart must be >= 1 (got %d)", maxstart);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = refresh_descriptors(ctx, lsoln != 0, stream);
+    if (rc != SAT_OK) return rc;
 
     SatKernelArgs a;
     a.orders = ctx->d_orders;
@@ -187,52 +246,57 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     a.tab_tri = ctx->d_tab;
     a.dist_tri = ctx->d_dist;
     a.ordinal = ctx->d_ordinal;
-    a.qdist = ctx->d_qdist;
-    a.qcode = ctx->d_qcode;
-    a.qtypes = ctx->d_qtypes;
-    a.n1 = ctx->n1;
     a.lorder = lorder ? 1 : 0;
     a.lsoln = lsoln ? 1 : 0;
     a.maxstart = maxstart;
-    a.seed_q = ctx->seed + ((uint64_t)ctx->query_ordinal << 32);
     a.ptab = ctx->d_ptab;
     a.prow = ctx->d_prow;
-    a.scores = ctx->d_scores;
-    a.ssemaps = ctx->d_ssemaps;
 
-    for (int b = 0; b < kNumBuckets; b++) {
-        const int count = ctx->bucket_begin[b + 1] - ctx->bucket_begin[b];
-        if (count == 0) continue;
-        const int n2max = ctx->bucket_n2max[b];
-        const int m2w = n2max <= 32 ? 1 : (n2max <= 64 ? 2 : 4);
+    for (int c = 0; c < 4; c++) {
+        const int nqc = ctx->class_begin[c + 1] - ctx->class_begin[c];
+        if (nqc == 0) continue;
+        const int n1p = kClassN1P[c], n1max = ctx->class_n1max[c];
+        a.queries = ctx->d_qdesc + ctx->class_begin[c];
+        for (int b = 0; b < kNumBuckets; b++) {
+            const int count = ctx->bucket_begin[b + 1] - ctx->bucket_begin[b];
+            if (count == 0) continue;
+            const int n2max = ctx->bucket_n2max[b];
+            const int m2w = n2max <= 32 ? 1 : (n2max <= 64 ? 2 : 4);
 
-        // threads: one lane per restart up to 256; shrink until the workgroup fits the LDS
-        int threads = (maxstart + 63) / 64 * 64;
-        if (threads > 256) threads = 256;
-        // query cells: through L1/L2 for 32-SSE-class queries and up (frees 8+ KB of LDS per
-        // workgroup: more resident waves), in LDS for the small class
-        bool qlds = ctx->n1p < 32;
-        if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || ctx->n1p < 32;
-        size_t lds = 0;
-        for (;;) {
-            lds = satk::lds_bytes(ctx->n1, ctx->n1p, n2max, threads, lsoln != 0, qlds);
-            if (lds <= kLdsLimit) break;
-            if (threads > 64) { threads -= 64; continue; }
-            if (qlds && ctx->n1p >= 64) {              // query cells stay in L1/L2 instead
-                qlds = false;
-                threads = (maxstart + 63) / 64 * 64;
-                if (threads > 256) threads = 256;
-                continue;
+            // threads: one lane per restart up to 256; shrink until the workgroup fits the LDS.
+            // query cells: through L1/L2 for 32-SSE-class queries and up (frees 8+ KB of LDS per
+            // workgroup: more resident waves), in LDS for the small class
+            int threads = (maxstart + 63) / 64 * 64;
+            if (threads > 256) threads = 256;
+            bool qlds = n1p < 32;
+            if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || n1p < 32;
+            size_t lds = 0;
+            for (;;) {
+                lds = satk::lds_bytes(n1max, n1p, n2max, threads, lsoln != 0, qlds);
+                if (lds <= kLdsLimit) break;
+                if (threads > 64) { threads -= 64; continue; }
+                if (qlds) {                                    // query cells stay in L1/L2 instead
+                    qlds = false;
+                    threads = (maxstart + 63) / 64 * 64;
+                    if (threads > 256) threads = 256;
+                    continue;
+                }
+                return fail(SAT_EINVAL, "workgroup does not fit in LDS (n1=%d n2=%d)", n1max, n2max);
             }
-            return fail(SAT_EINVAL, "workgroup does not fit in LDS (n1=%d n2=%d)", ctx->n1, n2max);
+            kernel_fn fn = pick_kernel(n1p, m2w, qlds);
+            if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            a.entry_list = ctx->d_lists + ctx->bucket_begin[b];
+            // grid.y is limited to 65535: split very long query lists
+            for (int q0 = 0; q0 < nqc; q0 += 65535) {
+                SatKernelArgs part = a;
+                part.queries = a.queries + q0;
+                const int qn = nqc - q0 < 65535 ? nqc - q0 : 65535;
+                hipLaunchKernelGGL(fn, dim3(count, qn), dim3(threads), lds, stream, part);
+                HIP_TRY(hipGetLastError());
+            }
         }
-        kernel_fn fn = pick_kernel(ctx->n1p, m2w, qlds);
-        if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", ctx->n1p, m2w);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-        a.entry_list = ctx->d_lists + ctx->bucket_begin[b];
-        hipLaunchKernelGGL(fn, dim3(count), dim3(threads), lds, stream, a);
-        HIP_TRY(hipGetLastError());
     }
     return SAT_OK;
 }
@@ -291,9 +355,8 @@ void sat_ctx_destroy(sat_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_db(ctx);
-    dev_free(ctx->d_qdist);
-    dev_free(ctx->d_qcode);
-    dev_free(ctx->d_qtypes);
+    dev_free(ctx->d_qblob);
+    dev_free(ctx->d_qdesc);
     dev_free(ctx->d_ptab);
     dev_free(ctx->d_prow);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -406,64 +469,93 @@ int sat_db_upload_dense(sat_ctx *ctx, int n_entries, const int32_t *orders,
 
 int sat_db_size(const sat_ctx *ctx) { return ctx ? ctx->n_entries : 0; }
 
+int sat_queries_set(sat_ctx *ctx, int n_queries, const int32_t *n1s, const uint8_t *qtabs,
+                    const float *qdmats, int pitch, const uint8_t *qssetypes, uint32_t first_query_ordinal)
+{
+    if (!ctx) return fail(SAT_EINVAL, "null context");
+    if (n_queries < 1 || !n1s || !qtabs || !qdmats || !qssetypes || pitch < 1)
+        return fail(SAT_EINVAL, "bad query batch (n_queries=%d pitch=%d)", n_queries, pitch);
+    std::vector<sat_ctx::QueryInfo> infos((size_t)n_queries);
+    size_t blob_bytes = 0;
+    for (int qi = 0; qi < n_queries; qi++) {
+        const int n1 = n1s[qi];
+        if (n1 < 1 || n1 > SAT_MAXDIM || n1 > pitch)
+            return fail(SAT_EINVAL, "query %d: order %d outside 1..min(%d, pitch %d)", qi, n1, SAT_MAXDIM, pitch);
+        auto &q = infos[(size_t)qi];
+        q.n1 = n1;
+        q.n1p = n1 <= 16 ? 16 : (n1 <= 32 ? 32 : (n1 <= 64 ? 64 : 112));
+        q.ordinal = first_query_ordinal + (uint32_t)qi;
+        q.blob_off = blob_bytes;
+        q.ssemap_off = 0;
+        const size_t groups = (size_t)q.n1p / 4 * q.n1p;
+        blob_bytes += (groups * 20 + (size_t)q.n1p + 15) & ~(size_t)15;
+    }
+    // grouped, transposed query: group kw, column i holds dmat1[i][4kw..4kw+3] and the four code
+    // bytes tab1[i][4kw..4kw+3]; diagonal, padding and non-finite distances get the sentinel
+    // so they never score (the reference excludes k == i, K.cu:524, and NaN never passes <= 4)
+    std::vector<uint8_t> blob(blob_bytes, 0);
+    for (int qi = 0; qi < n_queries; qi++) {
+        const auto &q = infos[(size_t)qi];
+        const int n1 = q.n1, n1p = q.n1p, groups = n1p / 4;
+        const uint8_t *qtab = qtabs + (size_t)qi * pitch * pitch;
+        const float *qdmat = qdmats + (size_t)qi * pitch * pitch;
+        const uint8_t *types = qssetypes + (size_t)qi * pitch;
+        float4 *qdist = reinterpret_cast<float4 *>(blob.data() + q.blob_off);
+        uint32_t *qcode = reinterpret_cast<uint32_t *>(blob.data() + q.blob_off + (size_t)groups * n1p * 16);
+        uint8_t *qtypes = blob.data() + q.blob_off + (size_t)groups * n1p * 20;
+        for (int i = 0; i < n1; i++) {
+            if (types[i] > 3)
+                return fail(SAT_EINVAL, "query %d: SSE %d has type code %u (0..3 expected)", qi, i, types[i]);
+            qtypes[i] = types[i];
+        }
+        for (int kw = 0; kw < groups; kw++)
+            for (int i = 0; i < n1p; i++) {
+                float d[4];
+                uint32_t codes = 0;
+                for (int sidx = 0; sidx < 4; sidx++) {
+                    const int k = 4 * kw + sidx;
+                    d[sidx] = SAT_K_QSENT;
+                    if (k < n1 && i < n1 && k != i) {
+                        const float v = qdmat[(size_t)i * pitch + k];
+                        const uint32_t code = qtab[(size_t)i * pitch + k];
+                        if (code & 0x88)
+                            return fail(SAT_EINVAL, "query %d: tableau code 0x%02x at (%d,%d) has a nibble above 7", qi, code, i, k);
+                        if (std::isfinite(v)) {
+                            if (std::fabs(v) >= 1.0e29f)
+                                return fail(SAT_EINVAL, "query %d: distance %g at (%d,%d) out of range", qi, v, i, k);
+                            d[sidx] = v;
+                        }
+                        codes |= code << (8 * sidx);
+                    }
+                }
+                qdist[(size_t)kw * n1p + i] = float4{ d[0], d[1], d[2], d[3] };
+                qcode[(size_t)kw * n1p + i] = codes;
+            }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_qblob);
+    dev_free(ctx->d_qdesc);
+    HIP_TRY(hipMalloc(&ctx->d_qblob, blob_bytes));
+    HIP_TRY(hipMalloc(&ctx->d_qdesc, (size_t)n_queries * sizeof(SatQuery)));
+    HIP_TRY(hipMemcpy(ctx->d_qblob, blob.data(), blob_bytes, hipMemcpyHostToDevice));
+    ctx->queries.swap(infos);
+    ctx->desc_dirty = true;
+    return SAT_OK;
+}
+
 int sat_query_set(sat_ctx *ctx, int n1, const uint8_t *qtab, const float *qdmat,
                   int pitch, const uint8_t *qssetypes, uint32_t query_ordinal)
 {
     if (!ctx) return fail(SAT_EINVAL, "null context");
     if (n1 < 1 || n1 > SAT_MAXDIM || !qtab || !qdmat || !qssetypes || pitch < n1)
         return fail(SAT_EINVAL, "bad query (n1=%d pitch=%d)", n1, pitch);
-    for (int i = 0; i < n1; i++)
-        if (qssetypes[i] > 3) return fail(SAT_EINVAL, "query SSE %d has type code %u (0..3 expected)", i, qssetypes[i]);
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const int n1p = n1 <= 16 ? 16 : (n1 <= 32 ? 32 : (n1 <= 64 ? 64 : 112));
-
-    // grouped, transposed query: group kw, column i holds dmat1[i][4kw..4kw+3] and the four code
-    // bytes tab1[i][4kw..4kw+3]; diagonal, padding and non-finite distances get the sentinel
-    // so they never score (the reference excludes k == i, K.cu:524, and NaN never passes <= 4)
-    const int groups = n1p / 4;
-    std::vector<float4> qdist((size_t)groups * n1p);
-    std::vector<uint32_t> qcode((size_t)groups * n1p);
-    for (int kw = 0; kw < groups; kw++)
-        for (int i = 0; i < n1p; i++) {
-            float d[4];
-            uint32_t codes = 0;
-            for (int sidx = 0; sidx < 4; sidx++) {
-                const int k = 4 * kw + sidx;
-                d[sidx] = SAT_K_QSENT;
-                if (k < n1 && i < n1 && k != i) {
-                    const float v = qdmat[(size_t)i * pitch + k];
-                    const uint32_t code = qtab[(size_t)i * pitch + k];
-                    if (code & 0x88)
-                        return fail(SAT_EINVAL, "query tableau code 0x%02x at (%d,%d) has a nibble above 7", code, i, k);
-                    if (std::isfinite(v)) {
-                        if (std::fabs(v) >= 1.0e29f)
-                            return fail(SAT_EINVAL, "query distance %g at (%d,%d) out of range", v, i, k);
-                        d[sidx] = v;
-                    }
-                    codes |= code << (8 * sidx);
-                }
-            }
-            qdist[(size_t)kw * n1p + i] = float4{ d[0], d[1], d[2], d[3] };
-            qcode[(size_t)kw * n1p + i] = codes;
-        }
-    std::vector<uint8_t> types((size_t)n1p, 0);
-    memcpy(types.data(), qssetypes, (size_t)n1);
-
-    dev_free(ctx->d_qdist);
-    dev_free(ctx->d_qcode);
-    dev_free(ctx->d_qtypes);
-    HIP_TRY(hipMalloc(&ctx->d_qdist, qdist.size() * sizeof(float4)));
-    HIP_TRY(hipMalloc(&ctx->d_qcode, qcode.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&ctx->d_qtypes, types.size()));
-    HIP_TRY(hipMemcpy(ctx->d_qdist, qdist.data(), qdist.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_qcode, qcode.data(), qcode.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_qtypes, types.data(), types.size(), hipMemcpyHostToDevice));
-    ctx->n1 = n1;
-    ctx->n1p = n1p;
-    ctx->query_ordinal = query_ordinal;
-    return SAT_OK;
+    // a batch of one; the type vector is only read up to n1, so its stride does not matter
+    const int32_t n1s[1] = { n1 };
+    return sat_queries_set(ctx, 1, n1s, qtab, qdmat, pitch, qssetypes, query_ordinal);
 }
+
+int sat_query_count(const sat_ctx *ctx) { return ctx ? (int)ctx->queries.size() : 0; }
 
 int sat_use_stream(sat_ctx *ctx, void *hip_stream)
 {
@@ -491,7 +583,7 @@ int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart)
 
 void *sat_device_scores(sat_ctx *ctx) { return ctx ? ctx->d_scores : nullptr; }
 void *sat_device_ssemaps(sat_ctx *ctx) { return ctx ? ctx->d_ssemaps : nullptr; }
-int sat_query_order(const sat_ctx *ctx) { return ctx ? ctx->n1 : 0; }
+int sat_query_order(const sat_ctx *ctx) { return (ctx && !ctx->queries.empty()) ? ctx->queries[0].n1 : 0; }
 
 int sat_sync(sat_ctx *ctx)
 {
@@ -507,17 +599,23 @@ int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps)
     if (!scores) return fail(SAT_EINVAL, "scores buffer is null");
     if (lsoln && !ssemaps) return fail(SAT_EINVAL, "lsoln set but ssemaps buffer is null");
     if (ctx->n_entries <= 0) return fail(SAT_ESTATE, "no database uploaded");
+    if (ctx->queries.empty() || !ctx->d_scores) return fail(SAT_ESTATE, "no search has run");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(scores, ctx->d_scores, (size_t)ctx->n_entries * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const size_t nq = ctx->queries.size(), N = (size_t)ctx->n_entries;
+    HIP_TRY(hipMemcpy(scores, ctx->d_scores, nq * N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (lsoln) {
-        const int n1 = ctx->n1;
-        if (!ctx->d_ssemaps) return fail(SAT_ESTATE, "no search with lsoln has run");
-        std::vector<int8_t> packed((size_t)ctx->n_entries * n1);
-        HIP_TRY(hipMemcpy(packed.data(), ctx->d_ssemaps, packed.size(), hipMemcpyDeviceToHost));
-        for (int e = 0; e < ctx->n_entries; e++)
-            for (int i = 0; i < n1; i++)
-                ssemaps[(size_t)e * SAT_MAXDIM + i] = packed[(size_t)e * n1 + i];
+        if (!ctx->d_ssemaps || !ctx->desc_lsoln) return fail(SAT_ESTATE, "no search with lsoln has run");
+        std::vector<int8_t> packed;
+        for (size_t qi = 0; qi < nq; qi++) {
+            const auto &q = ctx->queries[qi];
+            packed.resize(N * q.n1);
+            HIP_TRY(hipMemcpy(packed.data(), ctx->d_ssemaps + q.ssemap_off, packed.size(), hipMemcpyDeviceToHost));
+            int32_t *out = ssemaps + qi * N * SAT_MAXDIM;
+            for (size_t e = 0; e < N; e++)
+                for (int i = 0; i < q.n1; i++)
+                    out[e * SAT_MAXDIM + i] = packed[e * q.n1 + i];
+        }
     }
     return SAT_OK;
 }

@@ -66,6 +66,19 @@
 #define SAT_K_QSENT 1.0e30f            // query-side "never within 4 A" distance
 #define SAT_K_DSENT (-1.0e30f)         // db-side sentinel (null SSE, non-finite input)
 
+// One query of a batch; a launch covers (db entries of one size bucket) x (queries of one
+// size class): blockIdx.x picks the entry, blockIdx.y the query.
+struct SatQuery {
+    const float4   *qdist;        // [N1P/4][N1P] distances of 4 consecutive query SSEs (transposed)
+    const uint32_t *qcode;        // [N1P/4][N1P] their 4 code bytes
+    const uint8_t  *qtypes;       // [N1P]
+    int32_t         n1;
+    uint32_t        pad_;
+    uint64_t        seed_q;       // seed + (query ordinal << 32)
+    int32_t        *scores;       // [N] this query's score row
+    int8_t         *ssemaps;      // [N][n1] this query's maps, -1 = unmatched
+};
+
 struct SatKernelArgs {
     // database shard (HBM)
     const int32_t  *orders;       // [N]
@@ -74,20 +87,13 @@ struct SatKernelArgs {
     const float    *dist_tri;     // packed lower triangles, distances
     const uint32_t *ordinal;      // [N] db file-order ordinal (stream key)
     const int32_t  *entry_list;   // entries handled by this launch (one per workgroup)
-    // query
-    const float4   *qdist;        // [N1P/4][N1P] distances of 4 consecutive query SSEs (transposed)
-    const uint32_t *qcode;        // [N1P/4][N1P] their 4 code bytes
-    const uint8_t  *qtypes;       // [N1P]
-    int32_t         n1;
+    // queries of this launch's size class
+    const SatQuery *queries;
     // options
     int32_t         lorder, lsoln, maxstart;
-    uint64_t        seed_q;       // seed + (query ordinal << 32)
     // Metropolis table
     const float    *ptab;         // ragged rows
     const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
-    // results
-    int32_t        *scores;       // [N]
-    int8_t         *ssemaps;      // [N][n1], -1 = unmatched
 };
 
 namespace satk {
@@ -271,7 +277,8 @@ sat_sa_kernel(const SatKernelArgs a)
     const int tid = threadIdx.x;
     const int T = blockDim.x;
     const int e = a.entry_list[blockIdx.x];
-    const int n1 = a.n1;
+    const SatQuery Q = a.queries[blockIdx.y];
+    const int n1 = Q.n1;
     const int n2 = a.orders[e];
     const int n2p = n2 + 1;
     const int n1w = (n1 + 3) >> 2;
@@ -289,8 +296,8 @@ sat_sa_kernel(const SatKernelArgs a)
     uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * T : 0);
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
     unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
-    const float4 *qdist = QLDS ? qdistL : a.qdist;
-    const uint32_t *qcode = QLDS ? qcodeL : a.qcode;
+    const float4 *qdist = QLDS ? qdistL : Q.qdist;
+    const uint32_t *qcode = QLDS ? qcodeL : Q.qcode;
 
     // ---- stage the db entry: packed lower triangle (HBM) -> full cell matrix (LDS)
     {
@@ -315,12 +322,12 @@ sat_sa_kernel(const SatKernelArgs a)
             Dc[c] = cell;
         }
         if (tid < 16) tmask[tid] = 0u;
-        for (int i = tid; i < N1P; i += T) qtypes[i] = a.qtypes[i];
+        for (int i = tid; i < N1P; i += T) qtypes[i] = Q.qtypes[i];
         if (QLDS) {
             const int groups = n1w * N1P;
             for (int c = tid; c < groups; c += T) {
-                qdistL[c] = a.qdist[c];
-                qcodeL[c] = a.qcode[c];
+                qdistL[c] = Q.qdist[c];
+                qcodeL[c] = Q.qcode[c];
             }
         }
     }
@@ -355,7 +362,7 @@ sat_sa_kernel(const SatKernelArgs a)
             int j = 0;
             bool stopped = false;
             for (int i0 = 0; i0 < n1; i0 += 4) {
-                uint4 r = philox_block(a.seed_q, subseq, (uint32_t)(i0 >> 2));
+                uint4 r = philox_block(Q.seed_q, subseq, (uint32_t)(i0 >> 2));
                 uint32_t rv[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
@@ -403,7 +410,7 @@ sat_sa_kernel(const SatKernelArgs a)
 
         // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
         for (int iter = 0; iter < SAT_K_MAXITER; iter++) {
-            const uint4 r = philox_block(a.seed_q, subseq, (uint32_t)(SAT_K_STEP_BLOCK0 + iter));
+            const uint4 r = philox_block(Q.seed_q, subseq, (uint32_t)(SAT_K_STEP_BLOCK0 + iter));
 
             // which query SSE moves (K.cu:1037-1042)
             const int ssei = scaled_index(to_uniform(r.x), n1);
@@ -505,10 +512,10 @@ sat_sa_kernel(const SatKernelArgs a)
     for (int w = 1; w < nwaves; w++) win = red[w] > win ? red[w] : win;
 
     const uint32_t win_restart = 0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu);
-    if (tid == 0) a.scores[e] = (int)(uint32_t)(win >> 32) - 0x40000000;
+    if (tid == 0) Q.scores[e] = (int)(uint32_t)(win >> 32) - 0x40000000;
     if (lsoln && any && best_restart == win_restart &&
         ((((unsigned long long)(uint32_t)(best + 0x40000000)) << 32) | (0xFFFFFFFFu - best_restart)) == win) {
-        int8_t *out = a.ssemaps + (size_t)e * n1;
+        int8_t *out = Q.ssemaps + (size_t)e * n1;
         for (int i = 0; i < n1; i++) {
             int j = bmap_b[map_byte_addr(i)];
             out[i] = (int8_t)(j == NULLJ ? -1 : j);

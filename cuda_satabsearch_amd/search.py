@@ -97,6 +97,33 @@ class Searcher:
         self._check(self._lib.sat_query_set(self._ctx, n1, qtab.ctypes.data, qdmat.ctypes.data, pitch,
                                             qssetypes.ctypes.data, int(query_ordinal)))
         self.n1 = n1
+        self.n_queries = 1
+        self._batch = False
+
+    def set_queries(self, queries, first_query_ordinal=0):
+        """Set a batch of queries scored together by one search(): `queries` is a list of
+        (qtab[n1, n1+], qdmat, qssetypes) triples.  search() then returns scores[nq, N]
+        (and ssemaps[nq, N, 111]); query q draws from the streams of ordinal
+        first_query_ordinal + q."""
+        nq = len(queries)
+        pitch = max(int(np.asarray(q[0]).shape[0]) for q in queries)
+        n1s = np.empty(nq, np.int32)
+        tabs = np.zeros((nq, pitch, pitch), np.uint8)
+        dmats = np.zeros((nq, pitch, pitch), np.float32)
+        types = np.zeros((nq, pitch), np.uint8)
+        for k, (t, d, ty) in enumerate(queries):
+            t = np.asarray(t, np.uint8)
+            d = np.asarray(d, np.float32)
+            n1 = t.shape[0]
+            n1s[k] = n1
+            tabs[k, :n1, :n1] = t[:, :n1]
+            dmats[k, :n1, :n1] = d[:, :n1]
+            types[k, :n1] = np.asarray(ty, np.uint8)[:n1] if ty is not None else np.diagonal(t)[:n1]
+        self._check(self._lib.sat_queries_set(self._ctx, nq, n1s.ctypes.data, tabs.ctypes.data, dmats.ctypes.data,
+                                              pitch, types.ctypes.data, int(first_query_ordinal)))
+        self.n1 = int(n1s[0])
+        self.n_queries = nq
+        self._batch = True
 
     def set_query_from(self, queries: StructSet, s, query_ordinal=None):
         t, d = queries.dense(s)
@@ -105,12 +132,15 @@ class Searcher:
     # ---- search -------------------------------------------------------------
     def search(self, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART):
         """Returns (scores int32[N], ssemaps int32[N, 111] or None, kernel_ms)."""
-        scores = np.empty(self.n_entries, np.int32)
-        ssemaps = np.full((self.n_entries, MAXDIM), -1, np.int32) if lsoln else None
+        nq = getattr(self, "n_queries", 1)
+        scores = np.empty((nq, self.n_entries), np.int32)
+        ssemaps = np.full((nq, self.n_entries, MAXDIM), -1, np.int32) if lsoln else None
         ms = C.c_double(0.0)
         self._check(self._lib.sat_search(self._ctx, int(bool(lorder)), int(bool(lsoln)), int(maxstart),
                                          scores.ctypes.data, ssemaps.ctypes.data if lsoln else None,
                                          C.byref(ms)))
+        if not getattr(self, "_batch", False):
+            return scores[0], (ssemaps[0] if lsoln else None), ms.value
         return scores, ssemaps, ms.value
 
     def use_stream(self, stream_handle):
@@ -128,10 +158,13 @@ class Searcher:
 
     def results(self, lsoln=False):
         """Wait for a queued search_async and fetch (scores, ssemaps or None)."""
-        scores = np.empty(self.n_entries, np.int32)
-        ssemaps = np.full((self.n_entries, MAXDIM), -1, np.int32) if lsoln else None
+        nq = getattr(self, "n_queries", 1)
+        scores = np.empty((nq, self.n_entries), np.int32)
+        ssemaps = np.full((nq, self.n_entries, MAXDIM), -1, np.int32) if lsoln else None
         self._check(self._lib.sat_results(self._ctx, int(bool(lsoln)), scores.ctypes.data,
                                           ssemaps.ctypes.data if lsoln else None))
+        if not getattr(self, "_batch", False):
+            return scores[0], (ssemaps[0] if lsoln else None)
         return scores, ssemaps
 
     def sync(self):
@@ -156,7 +189,7 @@ class Searcher:
 
         h = _Holder()
         h.__cuda_array_interface__ = {
-            "shape": (self.n_entries,), "typestr": "<i4", "data": (int(self.device_scores_ptr()), False),
+            "shape": (getattr(self, "n_queries", 1) * self.n_entries,), "typestr": "<i4", "data": (int(self.device_scores_ptr()), False),
             "version": 3, "strides": None,
         }
         return torch.as_tensor(h, device=f"cuda:{self.device}")

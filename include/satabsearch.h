@@ -103,7 +103,24 @@ int sat_query_set(sat_ctx *ctx, int n1, const uint8_t *qtab, const float *qdmat,
                   int pitch, const uint8_t *qssetypes, uint32_t query_ordinal);
 
 /*
- * Run the search for the current query over the resident shard and wait for it.
+ * Set a BATCH of queries that one sat_search scores together (grid = entries x queries
+ * inside the launches): query q occupies pitch*pitch cells at qtabs + q*pitch*pitch and
+ * qdmats + q*pitch*pitch, its SSE types pitch bytes at qssetypes + q*pitch, its order is
+ * n1s[q]; its stream key is first_query_ordinal + q.  The reference loops over queries
+ * with a sync, four cudaMemcpy and a launch each (H.cu:987-1115); query lists (-q) of
+ * hundreds of SIDs are its main workload, and a small database alone cannot fill the GPU.
+ * After this call every result buffer has one row per query, in the order given here.
+ */
+int sat_queries_set(sat_ctx *ctx, int n_queries, const int32_t *n1s, const uint8_t *qtabs,
+                    const float *qdmats, int pitch, const uint8_t *qssetypes,
+                    uint32_t first_query_ordinal);
+
+/* Queries currently set (1 after sat_query_set). */
+int sat_query_count(const sat_ctx *ctx);
+
+/*
+ * Run the search for the current query (or query batch) over the resident shard and wait.
+ * With a batch of nq queries: scores is [nq][n_entries], ssemaps [nq][n_entries*SAT_MAXDIM].
  * Replaces the sa_tabsearch_gpu / sa_tabsearch_gpu_noshared launches, their
  * cudaDeviceSynchronize and the result cudaMemcpy, H.cu:1036-1087, 1219-1253
  * (kernel contract K.cu:756-802):
@@ -135,9 +152,10 @@ int sat_use_own_stream(sat_ctx *ctx);
  * torch.distributed gather over RCCL): launches on the context's current stream,
  * does not synchronise and does not copy.  Results land in the context's device
  * buffers:
- *   sat_device_scores()   int32 [n_entries]
- *   sat_device_ssemaps()  int8  [n_entries * sat_query_order()], -1 = unmatched,
- *                         valid after a search with lsoln != 0
+ *   sat_device_scores()   int32 [n_queries][n_entries]
+ *   sat_device_ssemaps()  int8, query q's [n_entries][n1_q] block after those of queries
+ *                         0..q-1; -1 = unmatched; valid after a search with lsoln != 0
+ * sat_query_order() is the order of query 0.
  */
 int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart);
 void *sat_device_scores(sat_ctx *ctx);

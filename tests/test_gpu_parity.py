@@ -158,6 +158,42 @@ def test_dense_upload_equals_packed(searcher, small_db, golden_dir):
     assert np.array_equal(a, b)
 
 
+# ---------------------------------------------------------------- query batches
+def test_query_batch_equals_one_by_one(searcher, small_db, golden_dir):
+    """A batch (grid = entries x queries) gives, row by row, what single-query searches give:
+    mixed size classes (8, 13, 19, 101 SSEs), LSOLN maps, query ordinals first..first+3."""
+    qs = [load_query(golden_dir, "multiquery.input", 0), load_query(golden_dir, "multiquery.input", 1),
+          load_query(golden_dir, "d2phlb1.input"), load_query(golden_dir, "multiquery.input", 2)]
+    searcher.upload(small_db)
+    entries = np.arange(0, len(small_db), 9)
+    searcher.set_queries(qs, first_query_ordinal=5)
+    scores, maps, _ = searcher.search(True, True, 128)
+    assert scores.shape == (4, len(small_db)) and maps.shape == (4, len(small_db), 111)
+    for k, q in enumerate(qs):
+        osc, omaps, _ = oracle_lib.search(small_db, *q, True, True, 128, entries=entries, query_ordinal=5 + k)
+        assert np.array_equal(scores[k][entries], osc), f"query {k}"
+        assert np.array_equal(maps[k][entries], omaps), f"query {k}"
+    searcher.set_query(*qs[2], 7)
+    one, onemaps, _ = searcher.search(True, True, 128)
+    assert np.array_equal(one, scores[2]) and np.array_equal(onemaps, maps[2])
+
+
+def test_large_query_batch_on_small_db(searcher, small_db):
+    """-q style workload: many db members as queries against the same small database."""
+    pick = np.nonzero((small_db.orders >= 4) & (small_db.orders <= 40))[0][:48]
+    qs = [(*small_db.dense(int(s)), small_db.ssetypes(int(s))) for s in pick]
+    searcher.upload(small_db)
+    searcher.set_queries(qs)
+    scores, _, ms = searcher.search(True, False, 128)
+    # each query structure is in the database: its own entry is the top hit (or ties it)
+    for k, s in enumerate(pick):
+        assert scores[k][s] == scores[k].max()
+    k = 17
+    osc, _, _ = oracle_lib.search(small_db, *qs[k], True, False, 128, query_ordinal=k, entries=np.arange(0, 586, 13))
+    assert np.array_equal(scores[k][np.arange(0, 586, 13)], osc)
+    print(f"48 queries x 586 entries: {ms:.2f} ms -> {48 * 586 / ms * 1e3:,.0f} scorings/s")
+
+
 # ---------------------------------------------------------------- edge cases
 def test_degenerate_structures(searcher):
     """1-SSE structures, a query whose SSE types do not occur in an entry, all-'??' codes."""
