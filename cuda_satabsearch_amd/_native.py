@@ -99,6 +99,12 @@ def host_lib():
         lib.sat_set_free.restype = None
         lib.sat_read_structures.argtypes = [C.c_void_p, C.POINTER(StructSetC), C.c_char_p]
         lib.sat_read_structures.restype = C.c_int
+        lib.sat_read_structures_file.argtypes = [C.c_char_p, C.POINTER(StructSetC), C.c_char_p]
+        lib.sat_read_structures_file.restype = C.c_int
+        lib.sat_set_save_binary.argtypes = [C.POINTER(StructSetC), C.c_char_p]
+        lib.sat_set_load_binary.argtypes = [C.c_char_p, C.POINTER(StructSetC)]
+        lib.sat_distance_cell.argtypes = [C.c_char_p]
+        lib.sat_distance_cell.restype = C.c_float
         lib.sat_norm2.argtypes = [C.c_int, C.c_int, C.c_int]
         lib.sat_norm2.restype = C.c_double
         lib.sat_z_gumbel_trunc.argtypes = [C.c_double]

@@ -19,12 +19,15 @@
  * sequential drand48 stream, byte-identical to the reference's -c.  It is never a
  * fallback: without -c a missing GPU is an error.
  *
- * Extensions: -g N (GPUs to use, default all visible), -s SEED (Philox seed, default 1234).
+ * Extensions: -g N (GPUs to use, default all visible), -s SEED (Philox seed, default 1234),
+ * -b (keep a binary image `dbfile.satbin` beside the database and load it instead of
+ * parsing when it is newer than the ASCII file).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -79,19 +82,20 @@ int main(int argc, char *argv[])
 {
     char dbfile[SAT_MAX_LINE_LEN] = "";
     char buf[SAT_MAX_LINE_LEN];
-    int use_gpu = 1, querydbmode = 0, maxstart = 128, want_gpus = 0;
+    int use_gpu = 1, querydbmode = 0, maxstart = 128, want_gpus = 0, bincache = 0;
     unsigned long long seed = SAT_DEFAULT_SEED;
     int ltype = 0, lorder = 0, lsoln = 0;
     char cltype = 'F', clorder = 'F', clsoln = 'F';
     int c;
 
-    while ((c = getopt(argc, argv, "cq:r:g:s:")) != -1) {
+    while ((c = getopt(argc, argv, "cq:r:g:s:b")) != -1) {
         switch (c) {
         case 'c': use_gpu = 0; break;
         case 'q': querydbmode = 1; strncpy(dbfile, optarg, sizeof(dbfile) - 1); break;
         case 'r': maxstart = atoi(optarg); break;
         case 'g': want_gpus = atoi(optarg); break;
         case 's': seed = strtoull(optarg, NULL, 0); break;
+        case 'b': bincache = 1; break;
         default: usage(argv[0]);
         }
     }
@@ -153,10 +157,25 @@ int main(int argc, char *argv[])
         fprintf(stderr, "ERROR opening db file %s\n", dbfile);
         exit(1);
     }
+    fclose(dbfp);
     fprintf(stderr, "Loading database...\n");
     double t0 = now_ms();
-    int total = sat_read_structures(dbfp, &db, "database");
-    fclose(dbfp);
+    int total = -1;
+    char binpath[SAT_MAX_LINE_LEN + 16];
+    snprintf(binpath, sizeof(binpath), "%s.satbin", dbfile);
+    if (bincache) {
+        struct stat sa, sb;
+        if (stat(dbfile, &sa) == 0 && stat(binpath, &sb) == 0 && sb.st_mtime >= sa.st_mtime &&
+            sat_set_load_binary(binpath, &db) == 0) {
+            total = db.count;
+            fprintf(stderr, "(binary image %s)\n", binpath);
+        }
+    }
+    if (total < 0) {
+        total = sat_read_structures_file(dbfile, &db, "database");     /* mmap reader, same semantics */
+        if (total >= 0 && bincache && sat_set_save_binary(&db, binpath) != 0)
+            fprintf(stderr, "WARNING: could not write %s\n", binpath);
+    }
     if (total < 0) {
         fprintf(stderr, "ERROR loading database\n");
         exit(1);

@@ -17,8 +17,13 @@
  *     the first tableau row;
  *   - order > 111 is skipped with a warning (parsetableaux.c:457-465).
  */
+#include <ctype.h>
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "sat_parse.h"
 
 void sat_set_init(sat_struct_set *set)
@@ -199,4 +204,200 @@ void sat_set_expand(const sat_struct_set *set, int s, int pitch,
             dist_dense[(size_t)i * pitch + j] = d[c];
             dist_dense[(size_t)j * pitch + i] = d[c];
         }
+}
+
+/* ------------------------------------------------------------------ memory-image reader */
+
+typedef struct cursor { const char *p, *end; } cursor;
+
+static int is_space(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+static void skip_space(cursor *c)
+{
+    while (c->p < c->end && is_space(*c->p)) c->p++;
+}
+
+/* fscanf("%8s %d\n"): skip blanks, up to 8 non-blank chars, blanks, a decimal int, blanks */
+static int scan_header(cursor *c, char *name, int *order)
+{
+    skip_space(c);
+    int n = 0;
+    while (c->p < c->end && !is_space(*c->p) && n < SAT_LABELSIZE) name[n++] = *c->p++;
+    name[n] = '\0';
+    if (n == 0) return 0;
+    skip_space(c);
+    const char *q = c->p;
+    int neg = 0;
+    if (q < c->end && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
+    if (q >= c->end || !isdigit((unsigned char)*q)) return 1;        /* name read, order missing */
+    long v = 0;
+    while (q < c->end && isdigit((unsigned char)*q)) { v = v * 10 + (*q - '0'); if (v > 100000000) v = 100000000; q++; }
+    *order = (int)(neg ? -v : v);
+    c->p = q;
+    skip_space(c);
+    return 2;
+}
+
+/* fgets(): one line (without the newline) copied into the zero-filled buf */
+static void next_line(cursor *c, char *buf)
+{
+    memset(buf, 0, SAT_MAX_LINE_LEN);
+    int n = 0;
+    while (c->p < c->end && n < SAT_MAX_LINE_LEN - 1) {
+        char ch = *c->p++;
+        if (ch == '\n') break;
+        buf[n++] = ch;
+    }
+}
+
+/* strtof(&buf[7j]) with a fast path for "[blanks][d]dd.ddd" followed by a blank or the end */
+static float distance_at(const char *p)
+{
+    const char *q = p;
+    while (*q == ' ') q++;
+    unsigned v = 0;
+    int nd = 0;
+    while (*q >= '0' && *q <= '9' && nd < 4) { v = v * 10 + (unsigned)(*q - '0'); q++; nd++; }
+    if (nd >= 1 && nd <= 3 && *q == '.' &&
+        q[1] >= '0' && q[1] <= '9' && q[2] >= '0' && q[2] <= '9' && q[3] >= '0' && q[3] <= '9' &&
+        (q[4] == ' ' || q[4] == '\0')) {
+        v = v * 1000 + (unsigned)(q[1] - '0') * 100 + (unsigned)(q[2] - '0') * 10 + (unsigned)(q[3] - '0');
+        /* == strtof() of the same text for every v < 10^6 (checked exhaustively in tests) */
+        return (float)((double)v / 1000.0);
+    }
+    return strtof(p, NULL);
+}
+
+float sat_distance_cell(const char *text)
+{
+    return distance_at(text);
+}
+
+int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, const char *what)
+{
+    static char buf[SAT_MAX_LINE_LEN];
+    uint8_t *tri_tab = (uint8_t *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2);
+    float *tri_dist = (float *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2 * sizeof(float));
+    char name[SAT_LABELSIZE + 1];
+    int order = 0, added = 0, skipped = 0;
+    cursor c = { text, text + len };
+
+    if (!tri_tab || !tri_dist) {
+        free(tri_tab);
+        free(tri_dist);
+        return -1;
+    }
+    while (c.p < c.end) {
+        if (scan_header(&c, name, &order) != 2)
+            break;
+        if (order > SAT_MAXDIM) {
+            fprintf(stderr, "Tableau %s order %d is too large (max is %d)\n", name, order, SAT_MAXDIM);
+            fprintf(stderr, "WARNING: excluded %s structure %s as it is too large\n", what, name);
+            for (int i = 0; i < 2 * order; i++)
+                next_line(&c, buf);
+            skipped++;
+            continue;
+        }
+        int64_t k = 0;
+        for (int i = 0; i < order; i++) {
+            next_line(&c, buf);
+            for (int j = 0; j <= i; j++, k++)
+                tri_tab[k] = (i == j) ? ssetype_code(&buf[3 * j]) : tableau_code(&buf[3 * j]);
+        }
+        k = 0;
+        for (int i = 0; i < order; i++) {
+            next_line(&c, buf);
+            for (int j = 0; j <= i; j++, k++)
+                tri_dist[k] = distance_at(&buf[7 * j]);
+        }
+        if (sat_set_append(set, name, order, tri_tab, tri_dist) < 0) {
+            free(tri_tab);
+            free(tri_dist);
+            return -1;
+        }
+        added++;
+    }
+    if (skipped > 0)
+        fprintf(stderr, "WARNING: skipped %d %s tableaux of order > %d\n", skipped, what, SAT_MAXDIM);
+    set->skipped += skipped;
+    free(tri_tab);
+    free(tri_dist);
+    return added;
+}
+
+int sat_read_structures_file(const char *path, sat_struct_set *set, const char *what)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return -1; }
+    if (st.st_size == 0) { close(fd); return 0; }
+    void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return -1;
+    (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+    int n = sat_read_structures_mem((const char *)map, (size_t)st.st_size, set, what);
+    munmap(map, (size_t)st.st_size);
+    return n;
+}
+
+/* ------------------------------------------------------------------ binary image */
+
+#define SAT_BIN_MAGIC "SATBIN01"
+
+int sat_set_save_binary(const sat_struct_set *set, const char *path)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    int64_t hdr[2] = { set->count, set->cells };
+    int ok = fwrite(SAT_BIN_MAGIC, 1, 8, f) == 8 && fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    size_t n = (size_t)set->count;
+    ok = ok && (n == 0 || (fwrite(set->order, sizeof(int), n, f) == n &&
+                           fwrite(set->name, SAT_LABELSIZE + 1, n, f) == n &&
+                           fwrite(set->cell_off, sizeof(int64_t), n, f) == n));
+    ok = ok && (set->cells == 0 || (fwrite(set->tab, 1, (size_t)set->cells, f) == (size_t)set->cells &&
+                                    fwrite(set->dist, sizeof(float), (size_t)set->cells, f) == (size_t)set->cells));
+    if (fclose(f) != 0) ok = 0;
+    return ok ? 0 : -1;
+}
+
+int sat_set_load_binary(const char *path, sat_struct_set *set)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    char magic[8];
+    int64_t hdr[2];
+    sat_struct_set tmp;
+    sat_set_init(&tmp);
+    int ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, SAT_BIN_MAGIC, 8) == 0 &&
+             fread(hdr, sizeof(hdr), 1, f) == 1 && hdr[0] >= 0 && hdr[0] < (1 << 30) && hdr[1] >= 0;
+    if (ok) {
+        size_t n = (size_t)hdr[0], cells = (size_t)hdr[1];
+        tmp.order = (int *)malloc(sizeof(int) * (n + 1));
+        tmp.name = (char *)malloc((SAT_LABELSIZE + 1) * (n + 1));
+        tmp.cell_off = (int64_t *)malloc(sizeof(int64_t) * (n + 1));
+        tmp.tab = (uint8_t *)malloc(cells + 1);
+        tmp.dist = (float *)malloc(sizeof(float) * (cells + 1));
+        ok = tmp.order && tmp.name && tmp.cell_off && tmp.tab && tmp.dist;
+        ok = ok && fread(tmp.order, sizeof(int), n, f) == n && fread(tmp.name, SAT_LABELSIZE + 1, n, f) == n &&
+             fread(tmp.cell_off, sizeof(int64_t), n, f) == n && fread(tmp.tab, 1, cells, f) == cells &&
+             fread(tmp.dist, sizeof(float), cells, f) == cells;
+        int64_t expect = 0;
+        for (size_t s = 0; ok && s < n; s++) {          /* offsets must be the running sum of the triangles */
+            int o = tmp.order[s];
+            ok = o <= SAT_MAXDIM && tmp.cell_off[s] == expect && tmp.name[s * (SAT_LABELSIZE + 1) + SAT_LABELSIZE] == '\0';
+            expect += o > 0 ? (int64_t)o * (o + 1) / 2 : 0;
+        }
+        ok = ok && expect == hdr[1];
+        tmp.count = tmp.capacity = (int)n;
+        tmp.cells = tmp.cells_cap = (int64_t)cells;
+    }
+    fclose(f);
+    if (!ok) {
+        sat_set_free(&tmp);
+        return -1;
+    }
+    sat_set_free(set);
+    *set = tmp;
+    return 0;
 }

@@ -63,6 +63,29 @@ int sat_set_append(sat_struct_set *set, const char *name, int order,
  */
 int sat_read_structures(FILE *fp, sat_struct_set *set, const char *what);
 
+/*
+ * Same grammar and cell semantics as sat_read_structures, from a memory image of the file
+ * (mmap): no stdio, and a fast path for the "%6.3f" distance cells the database builder
+ * writes; any cell that does not look like [ddd].ddd goes through strtof() as before.
+ * ~10x faster ingest for million-entry databases.
+ */
+int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, const char *what);
+
+/* One distance cell exactly as the memory-image reader parses it (exposed for the tests that
+ * compare the fast path with strtof over its whole domain). */
+float sat_distance_cell(const char *text);
+
+/* mmap `path` and parse it with sat_read_structures_mem; -1 if the file cannot be mapped. */
+int sat_read_structures_file(const char *path, sat_struct_set *set, const char *what);
+
+/*
+ * Binary image of a structure set (the packed arrays as they are, little endian):
+ * lets a command line skip the ASCII parse on later runs.  Returns 0 / -1.
+ * sat_set_load_binary refuses files whose header, sizes or offsets are inconsistent.
+ */
+int sat_set_save_binary(const sat_struct_set *set, const char *path);
+int sat_set_load_binary(const char *path, sat_struct_set *set);
+
 /* Expand structure s to dense symmetric pitch x pitch arrays (row-major). */
 void sat_set_expand(const sat_struct_set *set, int s, int pitch,
                     uint8_t *tab_dense, float *dist_dense);

@@ -28,14 +28,36 @@ class StructSet:
 
     # ---- construction -------------------------------------------------------
     @classmethod
-    def read(cls, path, what="database", skip_header_lines=0):
+    def _from_cset(cls, cset):
+        host = _native.host_lib()
+        count, cells = cset.count, cset.cells
+        orders = np.ctypeslib.as_array(cset.order, shape=(max(count, 1),))[:count].copy()
+        cell_off = np.ctypeslib.as_array(cset.cell_off, shape=(max(count, 1),))[:count].copy()
+        tab = np.ctypeslib.as_array(cset.tab, shape=(max(cells, 1),))[:cells].copy()
+        dist = np.ctypeslib.as_array(cset.dist, shape=(max(cells, 1),))[:cells].copy()
+        raw = C.string_at(cset.name, count * (_native.LABELSIZE + 1)) if count else b""
+        names = [raw[i * 9:(i + 1) * 9].split(b"\0", 1)[0].decode("latin-1") for i in range(count)]
+        host.sat_set_free(C.byref(cset))
+        return cls(orders, names, cell_off, tab, dist)
+
+    @classmethod
+    def read(cls, path, what="database", skip_header_lines=0, stdio=False):
         """Parse an ASCII tableau + distance-matrix file with the C reader.
 
-        skip_header_lines=2 skips the 'dbfile' and 'LTYPE LORDER LSOLN' lines of a query
-        file (the reference reads them with fscanf before read_queries,
-        cudaSaTabsearch.cu:667-684).
-        """
+        Whole files go through the mmap reader (sat_read_structures_file); with
+        skip_header_lines=2 the 'dbfile' and 'LTYPE LORDER LSOLN' lines of a query file
+        are skipped first (the reference reads them with fscanf before read_queries,
+        cudaSaTabsearch.cu:667-684) and the stdio reader is used.  stdio=True forces the
+        stdio reader (the one the reference's semantics were pinned with)."""
         host = _native.host_lib()
+        cset = _native.StructSetC()
+        host.sat_set_init(C.byref(cset))
+        if skip_header_lines == 0 and not stdio:
+            n = host.sat_read_structures_file(str(path).encode(), C.byref(cset), what.encode())
+            if n < 0:
+                host.sat_set_free(C.byref(cset))
+                raise OSError(f"cannot read {path}")
+            return cls._from_cset(cset)
         libc = _native.libc()
         fp = libc.fopen(str(path).encode(), b"r")
         if not fp:
@@ -44,23 +66,41 @@ class StructSet:
             buf = C.create_string_buffer(4096)
             for _ in range(skip_header_lines):
                 libc.fgets(buf, 4096, fp)
-            cset = _native.StructSetC()
-            host.sat_set_init(C.byref(cset))
             n = host.sat_read_structures(fp, C.byref(cset), what.encode())
             if n < 0:
                 host.sat_set_free(C.byref(cset))
                 raise MemoryError("sat_read_structures failed")
-            count, cells = cset.count, cset.cells
-            orders = np.ctypeslib.as_array(cset.order, shape=(max(count, 1),))[:count].copy()
-            cell_off = np.ctypeslib.as_array(cset.cell_off, shape=(max(count, 1),))[:count].copy()
-            tab = np.ctypeslib.as_array(cset.tab, shape=(max(cells, 1),))[:cells].copy()
-            dist = np.ctypeslib.as_array(cset.dist, shape=(max(cells, 1),))[:cells].copy()
-            raw = C.string_at(cset.name, count * (_native.LABELSIZE + 1)) if count else b""
-            names = [raw[i * 9:(i + 1) * 9].split(b"\0", 1)[0].decode("latin-1") for i in range(count)]
-            host.sat_set_free(C.byref(cset))
         finally:
             libc.fclose(fp)
-        return cls(orders, names, cell_off, tab, dist)
+        return cls._from_cset(cset)
+
+    def _to_cset(self):
+        """A StructSetC viewing this set's arrays (valid while self is alive)."""
+        cset = _native.StructSetC()
+        names = b"".join(n.encode("latin-1")[:8].ljust(9, b"\0") for n in self.names)
+        self._name_buf = C.create_string_buffer(names, len(names) + 1)
+        cset.count = cset.capacity = len(self)
+        cset.cells = cset.cells_cap = int(self.tab.size)
+        cset.order = self.orders.ctypes.data_as(C.POINTER(C.c_int))
+        cset.name = C.cast(self._name_buf, C.POINTER(C.c_char))
+        cset.cell_off = self.cell_off.ctypes.data_as(C.POINTER(C.c_int64))
+        cset.tab = self.tab.ctypes.data_as(C.POINTER(C.c_uint8))
+        cset.dist = self.dist.ctypes.data_as(C.POINTER(C.c_float))
+        return cset
+
+    def save_binary(self, path):
+        cset = self._to_cset()
+        if _native.host_lib().sat_set_save_binary(C.byref(cset), str(path).encode()) != 0:
+            raise OSError(f"cannot write {path}")
+
+    @classmethod
+    def load_binary(cls, path):
+        host = _native.host_lib()
+        cset = _native.StructSetC()
+        host.sat_set_init(C.byref(cset))
+        if host.sat_set_load_binary(str(path).encode(), C.byref(cset)) != 0:
+            raise OSError(f"{path} is not a valid structure-set image")
+        return cls._from_cset(cset)
 
     @classmethod
     def from_dense(cls, orders, tabs, dmats, names=None):

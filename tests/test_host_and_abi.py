@@ -100,3 +100,56 @@ def test_ascii_round_trip(tmp_path):
     assert np.array_equal(back.orders, db.orders)
     assert np.array_equal(back.tab, db.tab) and np.array_equal(back.dist, db.dist)
     assert back.names == db.names
+
+
+def test_fast_distance_cell_equals_strtof_on_its_whole_domain():
+    """The mmap reader's fast path turns "ddd.ddd" into float(v / 1000.0); strtof rounds the
+    decimal text directly.  Equal for every value the fast path accepts (v < 10^6)."""
+    import ctypes
+    host = _native.host_lib()
+    libc = ctypes.CDLL(None)
+    libc.strtof.restype = ctypes.c_float
+    libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    v = np.arange(1_000_000, dtype=np.int64)
+    fast = (v.astype(np.float64) / 1000.0).astype(np.float32)          # what distance_at computes
+    # numpy parses decimal text correctly rounded, like strtof; spot-check strtof itself below
+    text = np.char.add(np.char.add((v // 1000).astype(str), "."), np.char.zfill((v % 1000).astype(str), 3))
+    ref = text.astype(np.float32)
+    assert np.array_equal(fast, ref)
+    for s in [b"  0.000 ", b" 99.999 ", b"123.456 ", b"  4.501  0.000 ", b"  7.5", b"-1.250 ", b"1e2 ", b" nan ", b"", b"   "]:
+        a, b = host.sat_distance_cell(s), libc.strtof(s, None)
+        assert (a == b) or (np.isnan(a) and np.isnan(b)), s
+
+
+def test_mmap_reader_equals_stdio_reader(golden_dir, tmp_path):
+    for name in ["tableauxdistmatrixdb.small.ascii", "tableauxdistmatrixdb.test2.ascii", "d1qlpa_.ascii"]:
+        a = sat.StructSet.read(os.path.join(golden_dir, name))
+        b = sat.StructSet.read(os.path.join(golden_dir, name), stdio=True)
+        assert a.names == b.names and np.array_equal(a.orders, b.orders)
+        assert np.array_equal(a.tab, b.tab) and np.array_equal(a.dist, b.dist)
+    # the >= 100 A quirk and an oversized structure, through both readers
+    body = open(os.path.join(golden_dir, "d1twfa_.input")).read().split("\n", 2)[2]
+    big = sat.synth.make_db(1, 20)
+    (tmp_path / "q.ascii").write_text(body)
+    a = sat.StructSet.read(tmp_path / "q.ascii")
+    b = sat.StructSet.read(tmp_path / "q.ascii", stdio=True)
+    assert np.array_equal(a.dist, b.dist) and np.array_equal(a.tab, b.tab)
+    lines = ["toobig   112"] + ["e  " * (i + 1) for i in range(112)] + [" 0.000 " * (i + 1) for i in range(112)] + [""]
+    sat.synth.write_ascii(big, tmp_path / "tail.ascii")
+    (tmp_path / "mixed.ascii").write_text("\n".join(lines) + "\n" + (tmp_path / "tail.ascii").read_text())
+    a = sat.StructSet.read(tmp_path / "mixed.ascii")
+    b = sat.StructSet.read(tmp_path / "mixed.ascii", stdio=True)
+    assert len(a) == len(b) == 1 and a.names == big.names and np.array_equal(a.dist, big.dist)
+
+
+def test_binary_image_round_trip(tmp_path):
+    db = sat.synth.make_db(300, 3, 40)
+    db.save_binary(tmp_path / "db.satbin")
+    back = sat.StructSet.load_binary(tmp_path / "db.satbin")
+    assert back.names == db.names and np.array_equal(back.orders, db.orders)
+    assert np.array_equal(back.tab, db.tab) and np.array_equal(back.dist, db.dist) and np.array_equal(back.cell_off, db.cell_off)
+    bad = bytearray((tmp_path / "db.satbin").read_bytes())
+    bad[40] ^= 0x7F                                         # corrupt an order
+    (tmp_path / "bad.satbin").write_bytes(bytes(bad))
+    with pytest.raises(OSError):
+        sat.StructSet.load_binary(tmp_path / "bad.satbin")
