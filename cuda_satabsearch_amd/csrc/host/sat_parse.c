@@ -238,16 +238,19 @@ static int scan_header(cursor *c, char *name, int *order)
     return 2;
 }
 
-/* fgets(): one line (without the newline) copied into the zero-filled buf */
-static void next_line(cursor *c, char *buf)
+/* fgets(): one line (without the newline) copied into buf; everything after it is zero, as
+ * in the zero-filled stdio buffer (only the part the previous line dirtied is cleared) */
+static void next_line(cursor *c, char *buf, int *dirty)
 {
-    memset(buf, 0, SAT_MAX_LINE_LEN);
-    int n = 0;
-    while (c->p < c->end && n < SAT_MAX_LINE_LEN - 1) {
-        char ch = *c->p++;
-        if (ch == '\n') break;
-        buf[n++] = ch;
-    }
+    const char *nl = (const char *)memchr(c->p, '\n', (size_t)(c->end - c->p));
+    size_t n = nl ? (size_t)(nl - c->p) : (size_t)(c->end - c->p);
+    size_t take = n < SAT_MAX_LINE_LEN - 1 ? n : SAT_MAX_LINE_LEN - 1;
+    memcpy(buf, c->p, take);
+    if ((int)take < *dirty) memset(buf + take, 0, (size_t)*dirty - take);
+    buf[take] = '\0';
+    *dirty = (int)take;
+    /* a longer line would be continued by the next fgets call; same here */
+    c->p += take < n ? take : (nl ? n + 1 : n);
 }
 
 /* strtof(&buf[7j]) with a fast path for "[blanks][d]dd.ddd" followed by a blank or the end */
@@ -281,6 +284,8 @@ int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, c
     char name[SAT_LABELSIZE + 1];
     int order = 0, added = 0, skipped = 0;
     cursor c = { text, text + len };
+    int dirty = SAT_MAX_LINE_LEN - 1;
+    memset(buf, 0, SAT_MAX_LINE_LEN);
 
     if (!tri_tab || !tri_dist) {
         free(tri_tab);
@@ -294,19 +299,19 @@ int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, c
             fprintf(stderr, "Tableau %s order %d is too large (max is %d)\n", name, order, SAT_MAXDIM);
             fprintf(stderr, "WARNING: excluded %s structure %s as it is too large\n", what, name);
             for (int i = 0; i < 2 * order; i++)
-                next_line(&c, buf);
+                next_line(&c, buf, &dirty);
             skipped++;
             continue;
         }
         int64_t k = 0;
         for (int i = 0; i < order; i++) {
-            next_line(&c, buf);
+            next_line(&c, buf, &dirty);
             for (int j = 0; j <= i; j++, k++)
                 tri_tab[k] = (i == j) ? ssetype_code(&buf[3 * j]) : tableau_code(&buf[3 * j]);
         }
         k = 0;
         for (int i = 0; i < order; i++) {
-            next_line(&c, buf);
+            next_line(&c, buf, &dirty);
             for (int j = 0; j <= i; j++, k++)
                 tri_dist[k] = distance_at(&buf[7 * j]);
         }
