@@ -20,7 +20,7 @@ ABI_SYMBOLS = (
     "sat_last_error", "sat_abi_version", "sat_device_count", "sat_ctx_create", "sat_ctx_destroy",
     "sat_db_upload_packed", "sat_db_upload_dense", "sat_db_size", "sat_query_set", "sat_search",
     "sat_search_async", "sat_device_scores", "sat_device_ssemaps", "sat_query_order", "sat_sync",
-    "sat_search_timed", "sat_use_stream", "sat_use_own_stream", "sat_results", "sat_queries_set", "sat_query_count",
+    "sat_search_timed", "sat_use_stream", "sat_use_own_stream", "sat_results", "sat_queries_set", "sat_query_count", "sat_topk",
 )
 
 
@@ -74,6 +74,7 @@ def device_lib():
         lib.sat_queries_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_uint32]
         lib.sat_query_count.argtypes = [C.c_void_p]
+        lib.sat_topk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.sat_device_scores.argtypes = [C.c_void_p]
         lib.sat_device_scores.restype = C.c_void_p
         lib.sat_device_ssemaps.argtypes = [C.c_void_p]

@@ -48,8 +48,9 @@ def build_host(force=False):
 
 def build_device(force=False):
     out = os.path.join(PKG, "libsatabsearch.so")
-    srcs = [os.path.join(CSRC, "sat_capi.hip")]
-    deps = srcs + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(INC, "satabsearch.h")]
+    srcs = [os.path.join(CSRC, "sat_capi.hip"), os.path.join(CSRC, "sat_topk.hip")]
+    deps = srcs + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
+                   os.path.join(INC, "satabsearch.h")]
     if force or _stale(out, deps):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
               "-I", INC, "-I", CSRC, "-o", out] + srcs)

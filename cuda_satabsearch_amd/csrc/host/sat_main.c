@@ -20,6 +20,8 @@
  * fallback: without -c a missing GPU is an error.
  *
  * Extensions: -g N (GPUs to use, default all visible), -s SEED (Philox seed, default 1234),
+ * -k K (print only the K best rows per query, ranked on the GPU by raw score, ties in
+ * database order - the `sort -k 2,2nr | head` users run on the reference's output),
  * -b (keep a binary image `dbfile.satbin` beside the database and load it instead of
  * parsing when it is newer than the ASCII file).
  */
@@ -54,6 +56,8 @@ static void usage(const char *prog)
     fprintf(stderr, "  -r restarts : number of restarts. Default %d\n", 128);
     fprintf(stderr, "  -g gpus : number of GPUs to shard the database over. Default all\n");
     fprintf(stderr, "  -s seed : seed of the GPU random streams. Default %d\n", SAT_DEFAULT_SEED);
+    fprintf(stderr, "  -k K : print only the K best rows per query (GPU mode)\n");
+    fprintf(stderr, "  -b : cache the parsed database as dbfile.satbin\n");
     exit(1);
 }
 
@@ -82,13 +86,13 @@ int main(int argc, char *argv[])
 {
     char dbfile[SAT_MAX_LINE_LEN] = "";
     char buf[SAT_MAX_LINE_LEN];
-    int use_gpu = 1, querydbmode = 0, maxstart = 128, want_gpus = 0, bincache = 0;
+    int use_gpu = 1, querydbmode = 0, maxstart = 128, want_gpus = 0, bincache = 0, topk = 0;
     unsigned long long seed = SAT_DEFAULT_SEED;
     int ltype = 0, lorder = 0, lsoln = 0;
     char cltype = 'F', clorder = 'F', clsoln = 'F';
     int c;
 
-    while ((c = getopt(argc, argv, "cq:r:g:s:b")) != -1) {
+    while ((c = getopt(argc, argv, "cq:r:g:s:bk:")) != -1) {
         switch (c) {
         case 'c': use_gpu = 0; break;
         case 'q': querydbmode = 1; strncpy(dbfile, optarg, sizeof(dbfile) - 1); break;
@@ -96,6 +100,7 @@ int main(int argc, char *argv[])
         case 'g': want_gpus = atoi(optarg); break;
         case 's': seed = strtoull(optarg, NULL, 0); break;
         case 'b': bincache = 1; break;
+        case 'k': topk = atoi(optarg); break;
         default: usage(argv[0]);
         }
     }
@@ -372,6 +377,43 @@ int main(int argc, char *argv[])
         fprintf(stderr, "GPU execution time %f ms\n", ms);
         fprintf(stderr, "%f million iterations/sec\n",
                 ((double)total * nqb * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
+        if (topk > 0) {
+            /* best K per query: each GPU ranks its shard, the host merges ngpu x K candidates */
+            const int kk = topk < total ? topk : total;
+            int32_t *cand_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk * ngpu);
+            int32_t *cand_sc = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk * ngpu);
+            if (!cand_idx || !cand_sc) { fprintf(stderr, "malloc failed\n"); exit(1); }
+            for (int b = 0; b < nqb; b++) {
+                const int qs = qindex[q0 + b], n1 = n1s[b];
+                int nc = 0;
+                for (int g = 0; g < ngpu; g++) {
+                    int got = sat_topk(ctx[g], b, kk, cand_idx + nc, cand_sc + nc);
+                    if (got < 0) {
+                        fprintf(stderr, "GPU %d top-k failed: %s\n", g, sat_last_error());
+                        exit_status = 1;
+                        goto bye;
+                    }
+                    for (int i = 0; i < got; i++) cand_idx[nc + i] += shard_begin[g];
+                    nc += got;
+                }
+                print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
+                for (int r = 0; r < kk && r < nc; r++) {          /* selection of the merged head */
+                    int bestc = r;
+                    for (int c2 = r + 1; c2 < nc; c2++)
+                        if (cand_sc[c2] > cand_sc[bestc] || (cand_sc[c2] == cand_sc[bestc] && cand_idx[c2] < cand_idx[bestc]))
+                            bestc = c2;
+                    int32_t ti = cand_idx[r], ts = cand_sc[r];
+                    cand_idx[r] = cand_idx[bestc]; cand_sc[r] = cand_sc[bestc];
+                    cand_idx[bestc] = ti; cand_sc[bestc] = ts;
+                    const int s2 = cand_idx[r];
+                    print_row(sat_set_name(&db, s2), cand_sc[r], n1, db.order[s2],
+                              ssemaps ? ssemaps + ((size_t)b * total + s2) * SAT_MAXDIM : NULL, lsoln, 0);
+                }
+            }
+            free(cand_idx);
+            free(cand_sc);
+            continue;
+        }
         for (int b = 0; b < nqb; b++) {
             const int qi = q0 + b, qs = qindex[qi], n1 = n1s[b];
             const int32_t *qscores = scores + (size_t)b * total;
@@ -391,7 +433,7 @@ int main(int argc, char *argv[])
             }
         }
     }
-    if (cls_count[1] > 0)
+    if (cls_count[1] > 0 && topk <= 0)
         for (int qi = 0; qi < num_queries; qi++) {
             const int qs = qindex[qi], n1 = qsrc->order[qs];
             print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);

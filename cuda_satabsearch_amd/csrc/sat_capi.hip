@@ -17,6 +17,7 @@
 
 #include "satabsearch.h"
 #include "sat_sa_kernel.hpp"
+#include "sat_ctx.hpp"
 
 namespace {
 
@@ -31,6 +32,19 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+}  // namespace
+
+int sat_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
         hipError_t err__ = (expr);                                                      \
@@ -41,7 +55,6 @@ int fail(int code, const char *fmt, ...)
 
 // db entries are launched in classes of similar order so that every launch sizes its
 // LDS for the largest member of the class only
-constexpr int kNumBuckets = 7;
 const int kBucketMax[kNumBuckets] = { 16, 32, 48, 64, 80, 96, 111 };
 constexpr size_t kLdsLimit = 160 * 1024;
 
@@ -52,46 +65,6 @@ template <typename T> void dev_free(T *&p)
 }
 
 }  // namespace
-
-struct sat_ctx {
-    int device = 0;
-    uint64_t seed = SAT_DEFAULT_SEED;
-    hipStream_t own_stream = nullptr;   // created with the context
-    hipStream_t stream = nullptr;       // where work is queued (own_stream unless sat_use_stream)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    // database shard
-    int n_entries = 0;
-    int32_t *d_orders = nullptr;
-    int64_t *d_cell_off = nullptr;
-    uint8_t *d_tab = nullptr;
-    float *d_dist = nullptr;
-    uint32_t *d_ordinal = nullptr;
-    int32_t *d_lists = nullptr;             // entry indices grouped by bucket
-    int bucket_begin[kNumBuckets + 1] = { 0 };
-    int bucket_n2max[kNumBuckets] = { 0 };
-    std::vector<int32_t> h_orders;
-
-    // queries (a batch; one query is a batch of 1), input order
-    struct QueryInfo { int n1, n1p; uint32_t ordinal; size_t blob_off; size_t ssemap_off; };
-    std::vector<QueryInfo> queries;
-    uint8_t *d_qblob = nullptr;             // per query: qdist | qcode | qtypes
-    SatQuery *d_qdesc = nullptr;            // descriptors grouped by size class
-    int class_begin[5] = { 0, 0, 0, 0, 0 };  // classes: n1p = 16, 32, 64, 112
-    int class_n1max[4] = { 0, 0, 0, 0 };
-    bool desc_dirty = true;
-    bool desc_lsoln = false;
-
-    // Metropolis table
-    float *d_ptab = nullptr;
-    int32_t *d_prow = nullptr;
-
-    // results: scores [nq][N]; ssemaps: query q's [N][n1_q] block at queries[q].ssemap_off
-    int32_t *d_scores = nullptr;
-    size_t scores_cap = 0;
-    int8_t *d_ssemaps = nullptr;
-    size_t ssemaps_cap = 0;
-};
 
 namespace {
 

@@ -167,6 +167,16 @@ class Searcher:
             return scores[0], (ssemaps[0] if lsoln else None)
         return scores, ssemaps
 
+    def topk(self, k, query=0):
+        """(entry_index int32[k'], scores int32[k']) of the best k hits of the last search,
+        sorted on the device by descending score, ties in database order."""
+        idx = np.empty(k, np.int32)
+        sc = np.empty(k, np.int32)
+        n = self._lib.sat_topk(self._ctx, int(query), int(k), idx.ctypes.data, sc.ctypes.data)
+        if n < 0:
+            self._check(n)
+        return idx[:n], sc[:n]
+
     def sync(self):
         self._check(self._lib.sat_sync(self._ctx))
 

@@ -175,6 +175,15 @@ int sat_sync(sat_ctx *ctx);
 int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps);
 
 /*
+ * Best-k hits of query `query` (0 for a single query) of the last search, selected and
+ * sorted on the device: entry_index[i] / scores_out[i] for i < k, by descending score, ties
+ * in database order - what `sort -k 2,2nr | head` does to the reference's output
+ * (README_example_usage.txt:100).  Returns the number of hits written (min(k, n_entries))
+ * or a negative SAT_E* code.  Waits for the queued search.
+ */
+int sat_topk(sat_ctx *ctx, int query, int k, int32_t *entry_index, int32_t *scores_out);
+
+/*
  * Time `repeats` back-to-back searches with HIP events on the launch stream
  * (inputs resident, no copies inside the window).  Returns total milliseconds
  * in *total_ms and the dominant SA kernel's summed device time in *kernel_ms.

@@ -79,3 +79,24 @@ def test_gpu_mode_query_list_and_large_class(tmp_path):
     assert a.returncode == 0, a.stderr.decode()[-400:]
     assert a.stdout == b.stdout
     assert a.stdout.count(b"# QUERY ID") == 4
+
+
+@pytest.mark.gpu
+def test_gpu_mode_topk_is_sorted_head_of_full_output(golden_dir):
+    full = run(CLI, golden_dir, ["-r", "128"], stdin_path="multiquery.input")
+    top = run(CLI, golden_dir, ["-r", "128", "-k", "7"], stdin_path="multiquery.input")
+    assert full.returncode == 0 and top.returncode == 0, top.stderr.decode()[-300:]
+    blocks, cur = [], None
+    for line in full.stdout.decode().splitlines():
+        if line.startswith("# cudaSaTabsearch"):
+            cur = {"head": [line], "rows": []}
+            blocks.append(cur)
+        elif line.startswith("#"):
+            cur["head"].append(line)
+        else:
+            cur["rows"].append(line)
+    expect = []
+    for b in blocks:
+        rows = sorted(enumerate(b["rows"]), key=lambda t: (-int(t[1].split()[1]), t[0]))[:7]
+        expect += b["head"] + [r for _, r in rows]
+    assert top.stdout.decode().splitlines() == expect

@@ -194,6 +194,19 @@ def test_large_query_batch_on_small_db(searcher, small_db):
     print(f"48 queries x 586 entries: {ms:.2f} ms -> {48 * 586 / ms * 1e3:,.0f} scorings/s")
 
 
+def test_device_topk(searcher, small_db, golden_dir):
+    qs = [load_query(golden_dir, "d2phlb1.input"), load_query(golden_dir, "multiquery.input", 1)]
+    searcher.upload(small_db)
+    searcher.set_queries(qs)
+    scores, _, _ = searcher.search(True, False, 128)
+    for qi in range(2):
+        idx, sc = searcher.topk(25, query=qi)
+        order = np.lexsort((np.arange(len(small_db)), -scores[qi].astype(np.int64)))[:25]
+        assert np.array_equal(idx, order) and np.array_equal(sc, scores[qi][order])
+    idx, sc = searcher.topk(10_000, query=0)          # k larger than the database
+    assert len(idx) == len(small_db) and (np.diff(sc) <= 0).all()
+
+
 # ---------------------------------------------------------------- edge cases
 def test_degenerate_structures(searcher):
     """1-SSE structures, a query whose SSE types do not occur in an entry, all-'??' codes."""
