@@ -236,26 +236,41 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             const int n2max = ctx->bucket_n2max[b];
             const int m2w = n2max <= 32 ? 1 : (n2max <= 64 ? 2 : 4);
 
-            // threads: one lane per restart up to 256; shrink until the workgroup fits the LDS.
+            // chains: one per restart up to 256; shrink until the workgroup fits the LDS.
             // query cells: through L1/L2 for 32-SSE-class queries and up (frees 8+ KB of LDS per
             // workgroup: more resident waves), in LDS for the small class
-            int threads = (maxstart + 63) / 64 * 64;
-            if (threads > 256) threads = 256;
+            int chains = (maxstart + 63) / 64 * 64;
+            if (chains > 256) chains = 256;
             bool qlds = n1p < 32;
             if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || n1p < 32;
             size_t lds = 0;
             for (;;) {
-                lds = satk::lds_bytes(n1max, n1p, n2max, threads, lsoln != 0, qlds);
+                lds = satk::lds_bytes(n1max, n1p, n2max, chains, lsoln != 0, qlds);
                 if (lds <= kLdsLimit) break;
-                if (threads > 64) { threads -= 64; continue; }
+                if (chains > 64) { chains -= 64; continue; }
                 if (qlds) {                                    // query cells stay in L1/L2 instead
                     qlds = false;
-                    threads = (maxstart + 63) / 64 * 64;
-                    if (threads > 256) threads = 256;
+                    chains = (maxstart + 63) / 64 * 64;
+                    if (chains > 256) chains = 256;
                     continue;
                 }
                 return fail(SAT_EINVAL, "workgroup does not fit in LDS (n1=%d n2=%d)", n1max, n2max);
             }
+            // lanes per chain: when LDS leaves fewer than ~3 waves per SIMD, let 2 or 4 adjacent
+            // lanes share a chain (same LDS, 2-4x the waves; they split the pair loops)
+            int lpc_shift = 0;
+            {
+                const int wgs = (int)(kLdsLimit / lds);
+                while (lpc_shift < 2 && wgs * ((chains << lpc_shift) / 64) < 12 && (chains << (lpc_shift + 1)) <= 1024 &&
+                       n1max > (8 << lpc_shift))
+                    lpc_shift++;
+                if (const char *ov = getenv("SAT_EXP_LPC")) {
+                    int v = atoi(ov);
+                    if (v >= 0 && v <= 2 && (chains << v) <= 1024) lpc_shift = v;
+                }
+            }
+            const int threads = chains << lpc_shift;
+            a.lpc_shift = lpc_shift;
             kernel_fn fn = pick_kernel(n1p, m2w, qlds);
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),

@@ -26,6 +26,12 @@
 //        (tid mod 32) - also conflict free.
 //   bmap same layout, best map so far (LSOLN only).
 //
+// Lanes per chain (lpc = 1, 2 or 4): when the cells of a large db entry leave room for
+// only a few workgroups per CU, lpc adjacent lanes run ONE chain together - every lane
+// does the cheap per-step bookkeeping redundantly (same stream, same decisions), each
+// takes every lpc-th map word of the pair loops and the partial sums are added across
+// the lanes - so a workgroup has lpc x the waves for the same LDS.
+//
 // Pair scores, four at a time (quad_terms): gfx950 issues and/or/xor/add/sub/lshr/
 // bitop3/f32 add at one wave64 op per ~2.4 clk and everything else (cmp, cndmask, bcnt,
 // perm, shifts left, SDWA, mad) at ~4.2 clk (profiles/r01_gfx950_valu_opcode_cost.txt), so
@@ -91,6 +97,7 @@ struct SatKernelArgs {
     const SatQuery *queries;
     // options
     int32_t         lorder, lsoln, maxstart;
+    int32_t         lpc_shift;    // log2(lanes per chain): 0, 1 or 2
     // Metropolis table
     const float    *ptab;         // ragged rows
     const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
@@ -248,17 +255,17 @@ __device__ __forceinline__ int scaled_index(float u, int n)
 }
 
 // LDS byte size of one workgroup
-__host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int threads, bool lsoln, bool q_in_lds)
+__host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains, bool lsoln, bool q_in_lds)
 {
     size_t n1w = (size_t)((n1 + 3) >> 2);
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
     dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
     size_t bytes = dcells * 8;
     if (q_in_lds) bytes += n1w * (size_t)n1p * 20;            // float4 + code dword per (group, column)
-    bytes += n1w * threads * 4 * (lsoln ? 2 : 1);
+    bytes += n1w * chains * 4 * (lsoln ? 2 : 1);
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
-    bytes += 8 * 8;                                           // reduction scratch (<= 8 waves... 4 used)
+    bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
     return bytes;
 }
 
@@ -267,15 +274,20 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int threads
 // N1P: pitch of the query cell matrix (>= 4*ceil(n1/4)); M2W: 32-bit words of a db-side
 // bit set (n2 <= 32*M2W); QLDS: query cells staged in LDS (else read through L1/L2).
 template <int N1P, int M2W, bool QLDS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 sat_sa_kernel(const SatKernelArgs a)
 {
     using namespace satk;
     constexpr int M1W = (N1P + 31) / 32;
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
-    const int tid = threadIdx.x;
-    const int T = blockDim.x;
+    const int lane_id = threadIdx.x;
+    const int nthreads = blockDim.x;
+    // chain = restart slot of this lane; `part` of `lpc` adjacent lanes share one chain
+    const int lpc = 1 << a.lpc_shift;
+    const int tid = lane_id >> a.lpc_shift;       // chain index inside the workgroup
+    const int part = lane_id & (lpc - 1);
+    const int T = nthreads >> a.lpc_shift;        // chains per workgroup
     const int e = a.entry_list[blockIdx.x];
     const SatQuery Q = a.queries[blockIdx.y];
     const int n1 = Q.n1;
@@ -304,7 +316,7 @@ sat_sa_kernel(const SatKernelArgs a)
         const uint8_t *tt = a.tab_tri + a.cell_off[e];
         const float *dd = a.dist_tri + a.cell_off[e];
         const int total = n2p * n2p;
-        for (int c = tid; c < total; c += T) {
+        for (int c = lane_id; c < total; c += nthreads) {
             int j = c / n2p;
             int l = c - j * n2p;
             uint2 cell;
@@ -321,18 +333,18 @@ sat_sa_kernel(const SatKernelArgs a)
             }
             Dc[c] = cell;
         }
-        if (tid < 16) tmask[tid] = 0u;
-        for (int i = tid; i < N1P; i += T) qtypes[i] = Q.qtypes[i];
+        if (lane_id < 16) tmask[lane_id] = 0u;
+        for (int i = lane_id; i < N1P; i += nthreads) qtypes[i] = Q.qtypes[i];
         if (QLDS) {
             const int groups = n1w * N1P;
-            for (int c = tid; c < groups; c += T) {
+            for (int c = lane_id; c < groups; c += nthreads) {
                 qdistL[c] = Q.qdist[c];
                 qcodeL[c] = Q.qcode[c];
             }
         }
     }
     __syncthreads();
-    for (int j = tid; j < n2; j += T) {
+    for (int j = lane_id; j < n2; j += nthreads) {
         int t = a.tab_tri[a.cell_off[e] + (int64_t)j * (j + 1) / 2 + j] & 3;   // diagonal = SSE type
         atomicOr(&tmask[t * 4 + (j >> 5)], 1u << (j & 31));
     }
@@ -394,13 +406,18 @@ sat_sa_kernel(const SatKernelArgs a)
         for (int i = 0; i < n1 - 1; i++) {
             const int j = smap_b[map_byte_addr(i)];
             const uint2 *drow = Dc + __mul24(j, n2p);
-            for (int kw = (i + 1) >> 2; kw < n1w; kw++) {
-                // pairs with k <= i inside the first word are switched off (wave-uniform mask)
+            auto row_group = [&](int kw) {
+                // pairs with k <= i inside the first word are switched off (mask from i and kw)
                 const int below = i + 1 - 4 * kw;
                 const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
                 score = quad_terms(qdist[kw * N1P + i], qcode[kw * N1P + i], drow, smap[kw * T + tid], force, score);
-            }
+            };
+            // one lane per chain: the group index stays in scalar registers
+            if (lpc == 1) for (int kw = (i + 1) >> 2; kw < n1w; kw++) row_group(kw);
+            else for (int kw = ((i + 1) >> 2) + part; kw < n1w; kw += lpc) row_group(kw);
         }
+        if (lpc >= 2) score += __shfl_xor(score, 1, 64);
+        if (lpc == 4) score += __shfl_xor(score, 2, 64);
         if (score > best) {
             best = score;
             best_restart = (uint32_t)restart;
@@ -453,14 +470,18 @@ sat_sa_kernel(const SatKernelArgs a)
             const uint2 *orow = Dc + __mul24(oldj, n2p);
             const uint2 *nrow = Dc + __mul24(newj, n2p);
             int sum_new = 0, sum_old = 0;
-            for (int kw = 0; kw < n1w; kw++) {
+            auto move_group = [&](int kw) {
                 const uint32_t word = smap[kw * T + tid];
                 const float4 qd = qdist[kw * N1P + ssei];
                 const uint32_t qc = qcode[kw * N1P + ssei];
                 sum_new = quad_terms(qd, qc, nrow, word, 0u, sum_new);
                 sum_old = quad_terms(qd, qc, orow, word, 0u, sum_old);
-            }
-            const int delta = sum_new - sum_old;
+            };
+            if (lpc == 1) for (int kw = 0; kw < n1w; kw++) move_group(kw);
+            else for (int kw = part; kw < n1w; kw += lpc) move_group(kw);
+            int delta = sum_new - sum_old;
+            if (lpc >= 2) delta += __shfl_xor(delta, 1, 64);
+            if (lpc == 4) delta += __shfl_xor(delta, 2, 64);
             const int newscore = score + delta;
 
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
@@ -505,15 +526,15 @@ sat_sa_kernel(const SatKernelArgs a)
         unsigned long long other = __shfl_xor(key, off, 64);
         key = other > key ? other : key;
     }
-    const int wave = tid >> 6, nwaves = (T + 63) >> 6;
-    if ((tid & 63) == 0) red[wave] = key;
+    const int wave = lane_id >> 6, nwaves = (nthreads + 63) >> 6;
+    if ((lane_id & 63) == 0) red[wave] = key;
     __syncthreads();
     unsigned long long win = red[0];
     for (int w = 1; w < nwaves; w++) win = red[w] > win ? red[w] : win;
 
     const uint32_t win_restart = 0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu);
-    if (tid == 0) Q.scores[e] = (int)(uint32_t)(win >> 32) - 0x40000000;
-    if (lsoln && any && best_restart == win_restart &&
+    if (lane_id == 0) Q.scores[e] = (int)(uint32_t)(win >> 32) - 0x40000000;
+    if (lsoln && any && part == 0 && best_restart == win_restart &&
         ((((unsigned long long)(uint32_t)(best + 0x40000000)) << 32) | (0xFFFFFFFFu - best_restart)) == win) {
         int8_t *out = Q.ssemaps + (size_t)e * n1;
         for (int i = 0; i < n1; i++) {
