@@ -308,8 +308,27 @@ sat_sa_kernel(const SatKernelArgs a)
     uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * T : 0);
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
     unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
-    const float4 *qdist = QLDS ? qdistL : Q.qdist;
-    const uint32_t *qcode = QLDS ? qcodeL : Q.qcode;
+    // query group (4 distances, 4 code bytes) of column `col`: from LDS, or from global memory
+    // through L1 - the descriptor's pointers are cast to the global address space so that the
+    // loads are global_load (a pointer read from memory is otherwise a generic "flat" pointer)
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f32x4_t *gptr_f4;
+    typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
+    const gptr_f4 qdistG = (gptr_f4)(uintptr_t)Q.qdist;
+    const gptr_u32 qcodeG = (gptr_u32)(uintptr_t)Q.qcode;
+    typedef const __attribute__((address_space(1))) char *gptr_c;
+    // uniform 64-bit base + 32-bit byte offset: the saddr form of global_load, no 64-bit VALU math
+    auto load_qdist = [&](uint32_t idx) -> float4 {
+        if constexpr (QLDS) return qdistL[idx];
+        else {
+            const f32x4_t v = *(gptr_f4)((gptr_c)qdistG + (idx << 4));
+            return float4{ v.x, v.y, v.z, v.w };
+        }
+    };
+    auto load_qcode = [&](uint32_t idx) -> uint32_t {
+        if constexpr (QLDS) return qcodeL[idx];
+        else return *(gptr_u32)((gptr_c)qcodeG + (idx << 2));
+    };
 
     // ---- stage the db entry: packed lower triangle (HBM) -> full cell matrix (LDS)
     {
@@ -410,7 +429,8 @@ sat_sa_kernel(const SatKernelArgs a)
                 // pairs with k <= i inside the first word are switched off (mask from i and kw)
                 const int below = i + 1 - 4 * kw;
                 const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
-                score = quad_terms(qdist[kw * N1P + i], qcode[kw * N1P + i], drow, smap[kw * T + tid], force, score);
+                const uint32_t qi = (uint32_t)(kw * N1P + i);
+                score = quad_terms(load_qdist(qi), load_qcode(qi), drow, smap[kw * T + tid], force, score);
             };
             // one lane per chain: the group index stays in scalar registers
             if (lpc == 1) for (int kw = (i + 1) >> 2; kw < n1w; kw++) row_group(kw);
@@ -472,8 +492,9 @@ sat_sa_kernel(const SatKernelArgs a)
             int sum_new = 0, sum_old = 0;
             auto move_group = [&](int kw) {
                 const uint32_t word = smap[kw * T + tid];
-                const float4 qd = qdist[kw * N1P + ssei];
-                const uint32_t qc = qcode[kw * N1P + ssei];
+                const uint32_t qi = (uint32_t)(kw * N1P + ssei);      // 32-bit offset from a uniform base
+                const float4 qd = load_qdist(qi);
+                const uint32_t qc = load_qcode(qi);
                 sum_new = quad_terms(qd, qc, nrow, word, 0u, sum_new);
                 sum_old = quad_terms(qd, qc, orow, word, 0u, sum_old);
             };
