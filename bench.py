@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--entries", type=int, default=PER_GPU_ENTRIES, help="db entries per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the N > 1 flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -103,12 +106,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # ---- inputs: this rank's contiguous shard of the synthetic database + the query
     n_local = args.entries
@@ -122,10 +130,15 @@ def main():
     # launch on torch's current stream: the RCCL gather and the timing events follow the kernel
     searcher.use_stream(torch.cuda.current_stream().cuda_stream)
 
+    def gather():
+        if args.backend == "nccl":
+            return sat.sharding.gather_to_rank0(scores_dev, total, world, rank, dist)
+        return sat.sharding.gather_to_rank0(scores_dev.cpu(), total, world, rank, dist)     # rehearsal path
+
     def step():
         searcher.search_async(True, False, MAXSTART)
         if world > 1:
-            sat.sharding.gather_to_rank0(scores_dev, total, world, rank, dist)
+            gather()
 
     def fence():
         torch.cuda.synchronize()
@@ -143,15 +156,19 @@ def main():
         searcher.search_async(True, False, MAXSTART)
         ev[2 * k + 1].record()
         if world > 1:
-            sat.sharding.gather_to_rank0(scores_dev, total, world, rank, dist)
+            gathered = gather()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = [ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(args.steps)]
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if rank == 0:
+            # the gathered array is the whole database in file order: shard 0 must be rank 0's own scores
+            assert gathered.shape[0] == total
+            assert torch.equal(gathered[:n_local].cpu(), scores_dev.cpu()[:n_local])
 
     if rank == 0:
         scorings = total * args.steps
