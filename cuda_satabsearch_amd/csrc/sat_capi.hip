@@ -90,6 +90,7 @@ int build_metropolis_table(sat_ctx *ctx)
         rows[2 * it] = (int32_t)tab.size();
         rows[2 * it + 1] = last;
         tab.insert(tab.end(), row.begin(), row.begin() + last + 1);
+        tab.push_back(0.0f);                         // entry last + 1: "can never be accepted"
         temp = temp * 0.95f;
     }
     HIP_TRY(hipMalloc(&ctx->d_ptab, tab.size() * sizeof(float)));

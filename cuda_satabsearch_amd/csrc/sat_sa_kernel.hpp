@@ -120,9 +120,11 @@ template <int W> __device__ __forceinline__ Bits<W> bits_below(int pos)
 {
     Bits<W> b;
     if constexpr (W == 1) {
-        // one word: ~(~0 << pos) for 0 < pos < 32, with the two saturating ends
-        uint32_t m = ~(0xFFFFFFFFu << (pos & 31));
-        b.w[0] = pos <= 0 ? 0u : (pos >= 32 ? 0xFFFFFFFFu : m);
+        // one word, full-rate ops only: all-ones shifted right by 32 - clamp(pos, 0, 32), done as
+        // two shifts of at most 16 so that a total of 32 really empties the word
+        const int s = 32 - min(max(pos, 0), 32);          // v_med3_i32
+        const int h = s >> 1;
+        b.w[0] = (0xFFFFFFFFu >> h) >> (s - h);
         return b;
     }
 #pragma unroll
@@ -477,14 +479,13 @@ sat_sa_kernel(const SatKernelArgs a)
                 for (int w = 0; w < M2W; w++)
                     cand.w[w] = tmask[t * 4 + w] & ~occ.w[w] & hi.w[w] & ~lo.w[w];
             }
+            // no candidate: the SSE becomes unmatched; one: it is taken without a draw
+            // (K.cu:701-702); several: the draw picks the (u - EPS) * cnt -th (K.cu:705-711).
+            // Branch-free: in a 64-lane wave every case occurs anyway.
             const int cnt = bits_count<M2W>(cand);
-            int newj = NULLJ;                                     // no candidate: the SSE becomes unmatched
-            if (cnt == 1) {
-                newj = bits_lowest<M2W>(cand);                    // K.cu:701-702, no draw
-            } else if (cnt > 1) {
-                const int pick = scaled_index(to_uniform(r.y), cnt);   // K.cu:705-711
-                newj = bits_select<M2W>(cand, pick);
-            }
+            const int pick = cnt > 1 ? scaled_index(to_uniform(r.y), cnt) : 0;
+            const int sel = bits_select<M2W>(cand, pick);
+            const int newj = cnt == 0 ? NULLJ : sel;
 
             // score change (deltasd, K.cu:502-535)
             const uint2 *orow = Dc + __mul24(oldj, n2p);
@@ -518,20 +519,36 @@ sat_sa_kernel(const SatKernelArgs a)
             // Metropolis: accept iff expf(delta / temp) > u, via the host-built table
             const float u = to_uniform(r.z);
             const int rowoff = a.prow[2 * iter], rowmax = a.prow[2 * iter + 1];
-            const int nd = -delta;
-            float p = 0.0f;
-            if (delta > 0) p = 2.0f;                              // expf(x > 0) > 1 >= u
-            else if (nd <= rowmax) p = a.ptab[rowoff + nd];
-            if (p > u) {
-                score = newscore;
-                smap_b[map_byte_addr(ssei)] = (uint8_t)newj;
-                if (oldj != NULLJ) bits_clear<M2W>(occ, oldj);
-                if (newj != NULLJ) {
-                    bits_set<M2W>(occ, newj);
-                    bits_set<M1W>(mapped, ssei);
+            // entry rowmax + 1 of every row is 0.0: larger -delta can never be accepted
+            const int nd = min(max(-delta, 0), rowmax + 1);
+            const float ptable = a.ptab[rowoff + nd];
+            const float p = delta > 0 ? 2.0f : ptable;            // expf(x > 0) > 1 >= u
+            const bool accept = p > u;
+            if (accept) smap_b[map_byte_addr(ssei)] = (uint8_t)newj;
+            score = accept ? newscore : score;
+            {
+                Bits<M2W> occ2 = occ;
+                Bits<M1W> mapped2 = mapped;
+                if constexpr (M2W == 1) {
+                    // bit n2 (the null SSE) must not be touched; n2 may be 32: mask by comparison
+                    const uint32_t oldbit = oldj != NULLJ ? (1u << (oldj & 31)) : 0u;
+                    const uint32_t newbit = newj != NULLJ ? (1u << (newj & 31)) : 0u;
+                    occ2.w[0] = (occ.w[0] & ~oldbit) | newbit;
                 } else {
-                    bits_clear<M1W>(mapped, ssei);
+                    if (oldj != NULLJ) bits_clear<M2W>(occ2, oldj);
+                    if (newj != NULLJ) bits_set<M2W>(occ2, newj);
                 }
+                if constexpr (M1W == 1) {
+                    const uint32_t ibit = 1u << ssei;
+                    mapped2.w[0] = newj != NULLJ ? (mapped.w[0] | ibit) : (mapped.w[0] & ~ibit);
+                } else {
+                    if (newj != NULLJ) bits_set<M1W>(mapped2, ssei);
+                    else bits_clear<M1W>(mapped2, ssei);
+                }
+#pragma unroll
+                for (int w = 0; w < M2W; w++) occ.w[w] = accept ? occ2.w[w] : occ.w[w];
+#pragma unroll
+                for (int w = 0; w < M1W; w++) mapped.w[w] = accept ? mapped2.w[w] : mapped.w[w];
             }
         }
     }
