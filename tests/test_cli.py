@@ -38,6 +38,18 @@ def test_host_mode_query_list(golden_dir):
     assert a.stdout == b.stdout and a.stdout.count(b"# QUERY ID") == 2
 
 
+def test_binary_image_cache_gives_identical_output(golden_dir, tmp_path):
+    import shutil
+    for f in ("tableauxdistmatrixdb.small.ascii", "c1_d1ubia_small.input"):
+        shutil.copy(os.path.join(golden_dir, f), tmp_path / f)
+    first = run(CLI, str(tmp_path), ["-c", "-r", "8", "-b"], stdin_path="c1_d1ubia_small.input")
+    assert first.returncode == 0 and (tmp_path / "tableauxdistmatrixdb.small.ascii.satbin").exists()
+    again = run(CLI, str(tmp_path), ["-c", "-r", "8", "-b"], stdin_path="c1_d1ubia_small.input")
+    plain = run(CLI, str(tmp_path), ["-c", "-r", "8"], stdin_path="c1_d1ubia_small.input")
+    assert b"binary image" in again.stderr and b"binary image" not in first.stderr
+    assert first.stdout == again.stdout == plain.stdout
+
+
 def test_input_errors(golden_dir):
     p = run(CLI, golden_dir, ["-c"], stdin_bytes=b"nosuchfile.ascii\nT T F\n" + open(os.path.join(golden_dir, "d1ubia_.input"), "rb").read().split(b"\n", 2)[2])
     assert p.returncode == 1 and b"ERROR opening db file" in p.stderr

@@ -256,6 +256,49 @@ def test_distance_threshold_boundary(searcher):
     assert len(set(scores.tolist())) > 1
 
 
+def test_non_finite_and_odd_distances(searcher):
+    """NaN / inf / negative / huge distances: the reference's float test |d1 - d2| <= 4 is
+    simply false for NaN and inf; the kernel maps them to its sentinel - same scores."""
+    rng = np.random.default_rng(11)
+    db = sat.synth.make_db(24, 10, 24, seed=3)
+    dist = db.dist.copy()
+    off = rng.choice(dist.size, 60, replace=False)
+    dist[off[:15]] = np.nan
+    dist[off[15:30]] = np.inf
+    dist[off[30:40]] = -np.inf
+    dist[off[40:50]] = -dist[off[40:50]]
+    dist[off[50:]] = 1.0e20
+    odd = sat.StructSet(db.orders, db.names, db.cell_off, db.tab, dist)
+    qt, qd, qtypes = sat.synth.planted_query(db, 5, keep=0.9)
+    qd = qd.copy()
+    qd[1, 3] = qd[3, 1] = np.nan
+    qd[2, 5] = qd[5, 2] = np.inf
+    searcher.upload(odd)
+    for lorder in (True, False):
+        check(searcher, odd, (qt, qd, qtypes), lorder, True, 128)
+
+
+def test_inputs_outside_the_kernel_domain_are_rejected():
+    with sat.Searcher(0) as s:
+        db = sat.synth.make_db(3, 6, 6)
+        tab = db.tab.copy()
+        tab[1] = 0x83                          # off-diagonal code with a nibble above 7
+        with pytest.raises(sat.SatError, match="nibble"):
+            s.upload(sat.StructSet(db.orders, db.names, db.cell_off, tab, db.dist))
+        dist = db.dist.copy()
+        dist[1] = 3.0e30
+        with pytest.raises(sat.SatError, match="out of range"):
+            s.upload(sat.StructSet(db.orders, db.names, db.cell_off, db.tab, dist))
+        s.upload(db)
+        qt, qd, qtypes = sat.synth.make_query(6)
+        bad = qt.copy(); bad[0, 1] = bad[1, 0] = 0x90
+        with pytest.raises(sat.SatError, match="nibble"):
+            s.set_query(bad, qd, qtypes)
+        qtypes2 = qtypes.copy(); qtypes2[0] = 9
+        with pytest.raises(sat.SatError, match="type code"):
+            s.set_query(qt, qd, qtypes2)
+
+
 def test_error_behaviour():
     with sat.Searcher(0) as s:
         with pytest.raises(sat.SatError, match="no database"):
