@@ -256,6 +256,39 @@ def test_distance_threshold_boundary(searcher):
     assert len(set(scores.tolist())) > 1
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_randomized_structures(searcher, seed):
+    """Random structures over the reader's whole alphabet (all 25 code combinations incl.
+    '?', all four SSE types) with distances on a coarse grid, so that |d1 - d2| lands on
+    exactly 4.0 and its float neighbours all the time; many orders, both LORDER modes."""
+    rng = np.random.default_rng(seed)
+    n = 90
+    orders = rng.integers(1, 41, n).astype(np.int32)
+    pmax = int(orders.max())
+    tabs = np.zeros((n, pmax, pmax), np.uint8)
+    dmats = np.zeros((n, pmax, pmax), np.float32)
+    grid = np.concatenate([np.arange(4, 30, 0.5), [8.0 + 2.0 ** -20, 12.0 - 2.0 ** -20, 16.0 + 2.0 ** -19]]).astype(np.float32)
+    for s_ in range(n):
+        m = int(orders[s_])
+        codes = (rng.integers(0, 5, (m, m)) << 4 | rng.integers(0, 5, (m, m))).astype(np.uint8)
+        codes = np.tril(codes, -1) + np.tril(codes, -1).T
+        d = rng.choice(grid, (m, m)).astype(np.float32)
+        d = np.tril(d, -1) + np.tril(d, -1).T
+        types = rng.integers(0, 4, m).astype(np.uint8) if rng.random() < 0.7 else np.full(m, rng.integers(0, 4), np.uint8)
+        codes[np.arange(m), np.arange(m)] = types
+        d[np.arange(m), np.arange(m)] = types
+        tabs[s_, :m, :m], dmats[s_, :m, :m] = codes, d
+    db = sat.StructSet.from_dense(orders, tabs, dmats)
+    searcher.upload(db)
+    for qsrc in rng.choice(np.nonzero(orders >= 3)[0], 3, replace=False):
+        m = int(orders[qsrc])
+        keep = np.sort(rng.choice(m, size=max(2, m - int(rng.integers(0, 3))), replace=False))
+        t, d = db.dense(int(qsrc))
+        q = (t[np.ix_(keep, keep)].copy(), d[np.ix_(keep, keep)].copy(), np.diagonal(t)[keep].copy())
+        check(searcher, db, q, True, True, 96)
+        check(searcher, db, q, False, True, 64)
+
+
 def test_non_finite_and_odd_distances(searcher):
     """NaN / inf / negative / huge distances: the reference's float test |d1 - d2| <= 4 is
     simply false for NaN and inf; the kernel maps them to its sentinel - same scores."""
