@@ -124,7 +124,9 @@ def main():
     db = sat.synth.make_db(n_local, ORDER, ORDER, first_index=rank * n_local, total=total)
     qt, qd, qtypes = sat.synth.make_query(ORDER)
     searcher = sat.Searcher(local_rank)
+    t_up = time.perf_counter()
     searcher.upload(db, db_ordinal=np.arange(rank * n_local, (rank + 1) * n_local))
+    upload_ms = (time.perf_counter() - t_up) * 1e3        # host -> HBM of the packed shard (synchronous copies)
     searcher.set_query(qt, qd, qtypes, 0)
     scores_dev = searcher.device_scores_tensor()
     # launch on torch's current stream: the RCCL gather and the timing events follow the kernel
@@ -197,6 +199,10 @@ def main():
                        "query_sses": ORDER, "db_entries": total, "restarts": MAXSTART,
                        "parallelism": "db-shard x%d" % world},
             "sa_steps_per_sec": value * MAXSTART * MAXITER,
+            # the boundary takes host buffers: one-off H->D of the shard, and the rate a single
+            # query would see with that copy included (never `value`)
+            "h2d_upload_ms": upload_ms,
+            "scorings_per_sec_incl_upload_single_query": total / (elapsed / args.steps + upload_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sat_sa_kernel<32,1,false>", "kernel_ms_avg": kavg_ms,

@@ -231,10 +231,22 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
         if (nqc == 0) continue;
         const int n1p = kClassN1P[c], n1max = ctx->class_n1max[c];
         a.queries = ctx->d_qdesc + ctx->class_begin[c];
+        // A small problem cannot fill the GPU: its run time is the latency of one workgroup per
+        // launch, so all order buckets go into ONE launch sized for the largest entry instead of
+        // one launch per bucket queued behind each other.
+        const bool one_launch = (long long)ctx->n_entries * nqc <= 4096;
+        int overall_n2max = 0;
+        for (int b = 0; b < kNumBuckets; b++)
+            if (ctx->bucket_n2max[b] > overall_n2max) overall_n2max = ctx->bucket_n2max[b];
         for (int b = 0; b < kNumBuckets; b++) {
-            const int count = ctx->bucket_begin[b + 1] - ctx->bucket_begin[b];
+            int count = ctx->bucket_begin[b + 1] - ctx->bucket_begin[b];
+            int n2max = ctx->bucket_n2max[b];
+            if (one_launch) {
+                if (b > 0) break;
+                count = ctx->n_entries;
+                n2max = overall_n2max;
+            }
             if (count == 0) continue;
-            const int n2max = ctx->bucket_n2max[b];
             const int m2w = n2max <= 32 ? 1 : (n2max <= 64 ? 2 : 4);
 
             // chains: one per restart up to 256; shrink until the workgroup fits the LDS.
@@ -276,7 +288,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-            a.entry_list = ctx->d_lists + ctx->bucket_begin[b];
+            a.entry_list = ctx->d_lists + (one_launch ? 0 : ctx->bucket_begin[b]);
             // grid.y is limited to 65535: split very long query lists
             for (int q0 = 0; q0 < nqc; q0 += 65535) {
                 SatKernelArgs part = a;
