@@ -186,12 +186,18 @@ def main():
                 traffic = t["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
+        metric = "db-structure scorings/sec (query\u00d7db pairs/sec) at r=128; 1/2/4/8 MI355X"
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
-            "metric": "db-structure scorings/sec (query x db pairs/sec) at r=128",
+            "metric": metric,
             "value": value, "unit": "db-structure scorings/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i32 scores over f32 distance / u8 tableau-code lookups",
+            "dtype": "i32",
+            "dtype_note": "integer pair scores; f32 distance comparisons and u8 tableau codes feed them",
             "data": "synthetic (seeded generator, cuda_satabsearch_amd/synth.py)",
             "config": {"workload": "32-SSE synthetic query x %d-entry synthetic db (32 SSEs per entry; %d per GPU), "
                                    "r=128 restarts x 100 SA steps, LTYPE=T LORDER=T LSOLN=F, contiguous db shards, "
