@@ -258,7 +258,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || n1p < 32;
             size_t lds = 0;
             for (;;) {
-                lds = satk::lds_bytes(n1max, n1p, n2max, chains, lsoln != 0, qlds);
+                lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains * 4, lsoln != 0, qlds);   // room for up to 4 lanes per chain
                 if (lds <= kLdsLimit) break;
                 if (chains > 64) { chains -= 64; continue; }
                 if (qlds) {                                    // query cells stay in L1/L2 instead

@@ -26,6 +26,16 @@
 //        (tid mod 32) - also conflict free.
 //   bmap same layout, best map so far (LSOLN only).
 //
+// Work compaction in the SA step (the db-scan regime is sparse: on random pairs ~25 % of
+// the query SSEs are matched, the moved SSE has a real old image in 25 % and a real new
+// one in 27 % of the steps, both in 10 %, neither in 58 %): instead of every lane scoring
+// 2 rows x n1/4 map words for its own chain, the lanes of a wave list the rows that are real
+// (ballot + mbcnt prefix -> a per-wave item table in LDS: row, moved SSE, owner chain,
+// sign), then the WHOLE wave works through (item, map word) pairs, 64 at a time, each lane
+// adding its four-pair sum to the owner's accumulator with an LDS atomic.  A wave-step then
+// costs ~S*n1w/64 packed evaluations (S = real rows in the wave, ~33 of 128) instead of
+// 2*n1w per lane.  When most rows are real (S large) the static per-lane loops run instead.
+//
 // Lanes per chain (lpc = 1, 2 or 4): when the cells of a large db entry leave room for
 // only a few workgroups per CU, lpc adjacent lanes run ONE chain together - every lane
 // does the cheap per-step bookkeeping redundantly (same stream, same decisions), each
@@ -257,7 +267,7 @@ __device__ __forceinline__ int scaled_index(float u, int n)
 }
 
 // LDS byte size of one workgroup
-__host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains, bool lsoln, bool q_in_lds)
+__host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains, int threads, bool lsoln, bool q_in_lds)
 {
     size_t n1w = (size_t)((n1 + 3) >> 2);
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
@@ -268,6 +278,8 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
     bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
+    bytes += (size_t)((threads + 63) / 64) * 128 * 4;         // per-wave item table (<= 2 rows per lane)
+    bytes += (size_t)chains * 4;                              // per-chain delta accumulator
     return bytes;
 }
 
@@ -310,6 +322,13 @@ sat_sa_kernel(const SatKernelArgs a)
     uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * T : 0);
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
     unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
+    // explicit LDS address space: these two are written by some lanes and read by others of the
+    // same wave between wavefront-scope fences, and must stay ds_* instructions
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+    typedef __attribute__((address_space(3))) int32_t lds_i32_t;
+    const uint32_t items_off = (uint32_t)(reinterpret_cast<unsigned char *>(red + 16) - lds_raw);
+    lds_u32_t *items = (lds_u32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)(lane_id >> 6) * 512u);
+    lds_i32_t *acc = (lds_i32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)((nthreads + 63) >> 6) * 512u);
     // query group (4 distances, 4 code bytes) of column `col`: from LDS, or from global memory
     // through L1 - the descriptor's pointers are cast to the global address space so that the
     // loads are global_load (a pointer read from memory is otherwise a generic "flat" pointer)
@@ -488,22 +507,73 @@ sat_sa_kernel(const SatKernelArgs a)
             const int newj = cnt == 0 ? NULLJ : sel;
 
             // score change (deltasd, K.cu:502-535)
-            const uint2 *orow = Dc + __mul24(oldj, n2p);
-            const uint2 *nrow = Dc + __mul24(newj, n2p);
-            int sum_new = 0, sum_old = 0;
-            auto move_group = [&](int kw) {
-                const uint32_t word = smap[kw * T + tid];
-                const uint32_t qi = (uint32_t)(kw * N1P + ssei);      // 32-bit offset from a uniform base
-                const float4 qd = load_qdist(qi);
-                const uint32_t qc = load_qcode(qi);
-                sum_new = quad_terms(qd, qc, nrow, word, 0u, sum_new);
-                sum_old = quad_terms(qd, qc, orow, word, 0u, sum_old);
-            };
-            if (lpc == 1) for (int kw = 0; kw < n1w; kw++) move_group(kw);
-            else for (int kw = part; kw < n1w; kw += lpc) move_group(kw);
-            int delta = sum_new - sum_old;
-            if (lpc >= 2) delta += __shfl_xor(delta, 1, 64);
-            if (lpc == 4) delta += __shfl_xor(delta, 2, 64);
+            int delta;
+            {
+                // rows of this step that are real, listed once per chain (part 0 of its lanes)
+                const bool oreal = oldj != NULLJ, nreal = newj != NULLJ;
+                const int nitems = part == 0 ? (int)oreal + (int)nreal : 0;
+                const unsigned long long m1 = __ballot(nitems >= 1), m2 = __ballot(nitems == 2);
+                const int total_items = __popcll(m1) + __popcll(m2);           // wave-uniform
+                // consumers are the lanes that are in this step at all (a wave's last lanes may
+                // have no restart left): work is dealt by rank among them
+                const unsigned long long active = __ballot(1);
+                const int nactive = __popcll(active);
+                const int gshift = n1w <= 1 ? 0 : 32 - __clz(n1w - 1);          // lanes per item = 2^gshift >= n1w
+                const int per_round = nactive >> gshift;
+                // compaction pays while the wave's (item, word) pairs fill fewer rounds than the
+                // two static rows per lane cost (a round is ~1.5x a static evaluation)
+                if (per_round > 0 && total_items * 3 <= per_round * (4 << gshift)) {
+                    const int lane64 = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0));
+                    const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0)) +
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
+                    if (part == 0) acc[tid] = 0;
+                    // item = row | moved SSE << 8 | owner chain << 16 | negate << 24
+                    if (nitems >= 1)
+                        items[pre] = (uint32_t)(oreal ? oldj : newj) | ((uint32_t)ssei << 8) | ((uint32_t)tid << 16) |
+                                     (oreal ? 1u << 24 : 0u);
+                    if (nitems == 2) items[pre + 1] = (uint32_t)newj | ((uint32_t)ssei << 8) | ((uint32_t)tid << 16);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // active-lane rank -> (item of the round, map word)
+                    const int sub = lane64 >> gshift, kw = lane64 & ((1 << gshift) - 1);
+                    for (int base = 0; base < total_items; base += per_round) {
+                        const int idx = base + sub;
+                        if (sub < per_round && idx < total_items && kw < n1w) {
+                            const uint32_t it = items[idx];
+                            const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
+                            const uint32_t word = smap[kw * T + owner];
+                            const uint32_t qi = (uint32_t)(kw * N1P + si);
+                            const int v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
+                            __hip_atomic_fetch_add(acc + owner, (it >> 24) ? -v : v,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    delta = total_items ? acc[tid] : 0;
+                } else {
+                    // dense regime: every lane scores its own two rows
+                    const uint2 *orow = Dc + __mul24(oldj, n2p);
+                    const uint2 *nrow = Dc + __mul24(newj, n2p);
+                    int sum_new = 0, sum_old = 0;
+                    auto move_group = [&](int kw) {
+                        const uint32_t word = smap[kw * T + tid];
+                        const uint32_t qi = (uint32_t)(kw * N1P + ssei);      // 32-bit offset from a uniform base
+                        const float4 qd = load_qdist(qi);
+                        const uint32_t qc = load_qcode(qi);
+                        sum_new = quad_terms(qd, qc, nrow, word, 0u, sum_new);
+                        sum_old = quad_terms(qd, qc, orow, word, 0u, sum_old);
+                    };
+                    if (lpc == 1) for (int kw = 0; kw < n1w; kw++) move_group(kw);
+                    else for (int kw = part; kw < n1w; kw += lpc) move_group(kw);
+                    delta = sum_new - sum_old;
+                    if (lpc >= 2) delta += __shfl_xor(delta, 1, 64);
+                    if (lpc == 4) delta += __shfl_xor(delta, 2, 64);
+                }
+            }
             const int newscore = score + delta;
 
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
