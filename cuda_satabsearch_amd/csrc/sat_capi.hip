@@ -254,11 +254,15 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             // workgroup: more resident waves), in LDS for the small class
             int chains = (maxstart + 63) / 64 * 64;
             if (chains > 256) chains = 256;
+            // work compaction needs sparse maps: with LORDER = F almost every step proposes a real
+            // new image, the static loops win and the tables would only cost LDS
+            bool compact = lorder != 0;
+            if (const char *ov = getenv("SAT_EXP_COMPACT")) compact = atoi(ov) != 0;
             bool qlds = n1p < 32;
             if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || n1p < 32;
             size_t lds = 0;
             for (;;) {
-                lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains * 4, lsoln != 0, qlds);   // room for up to 4 lanes per chain
+                lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains * 4, lsoln != 0, qlds, compact);   // room for 4 lanes per chain
                 if (lds <= kLdsLimit) break;
                 if (chains > 64) { chains -= 64; continue; }
                 if (qlds) {                                    // query cells stay in L1/L2 instead
@@ -284,6 +288,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             }
             const int threads = chains << lpc_shift;
             a.lpc_shift = lpc_shift;
+            a.compact = compact ? 1 : 0;
             kernel_fn fn = pick_kernel(n1p, m2w, qlds);
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),

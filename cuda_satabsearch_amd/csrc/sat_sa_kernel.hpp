@@ -108,6 +108,7 @@ struct SatKernelArgs {
     // options
     int32_t         lorder, lsoln, maxstart;
     int32_t         lpc_shift;    // log2(lanes per chain): 0, 1 or 2
+    int32_t         compact;      // 1: the SA step may use the wave-level work compaction (its LDS tables exist)
     // Metropolis table
     const float    *ptab;         // ragged rows
     const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
@@ -267,7 +268,8 @@ __device__ __forceinline__ int scaled_index(float u, int n)
 }
 
 // LDS byte size of one workgroup
-__host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains, int threads, bool lsoln, bool q_in_lds)
+__host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains, int threads, bool lsoln, bool q_in_lds,
+                                             bool compact)
 {
     size_t n1w = (size_t)((n1 + 3) >> 2);
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
@@ -278,8 +280,10 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
     bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
-    bytes += (size_t)((threads + 63) / 64) * 128 * 4;         // per-wave item table (<= 2 rows per lane)
-    bytes += (size_t)chains * 4;                              // per-chain delta accumulator
+    if (compact) {
+        bytes += (size_t)((threads + 63) / 64) * 128 * 4;     // per-wave item table (<= 2 rows per lane)
+        bytes += (size_t)chains * 4;                          // per-chain delta accumulator
+    }
     return bytes;
 }
 
@@ -520,9 +524,11 @@ sat_sa_kernel(const SatKernelArgs a)
                 const int nactive = __popcll(active);
                 const int gshift = n1w <= 1 ? 0 : 32 - __clz(n1w - 1);          // lanes per item = 2^gshift >= n1w
                 const int per_round = nactive >> gshift;
-                // compaction pays while the wave's (item, word) pairs fill fewer rounds than the
-                // two static rows per lane cost (a round is ~1.5x a static evaluation)
-                if (per_round > 0 && total_items * 3 <= per_round * (4 << gshift)) {
+                // cost model in SIMD cycles, from the opcode table: a round of the compacted loop is
+                // ~155 and its set-up ~100; the static loops cost ~85 per (row, word) = 170 per word.
+                // Full waves only (rank arithmetic stays shifts).
+                const int rounds = (total_items + per_round - 1) >> (6 - gshift);
+                if (a.compact && nactive == 64 && rounds * 155 + 100 < 170 * n1w) {
                     const int lane64 = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32),
                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0));
                     const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0)) +
