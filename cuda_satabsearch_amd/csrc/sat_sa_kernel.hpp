@@ -522,12 +522,13 @@ sat_sa_kernel(const SatKernelArgs a)
                 // have no restart left): work is dealt by rank among them
                 const unsigned long long active = __ballot(1);
                 const int nactive = __popcll(active);
-                const int gshift = n1w <= 1 ? 0 : 32 - __clz(n1w - 1);          // lanes per item = 2^gshift >= n1w
-                const int per_round = nactive >> gshift;
+                // n1w lanes per item; lane / n1w by a 16-bit reciprocal (exact for lane <= 64, n1w <= 28)
+                const int recip = (65536 + n1w - 1) / n1w;
+                const int per_round = (64 * recip) >> 16;
                 // cost model in SIMD cycles, from the opcode table: a round of the compacted loop is
                 // ~155 and its set-up ~100; the static loops cost ~85 per (row, word) = 170 per word.
                 // Full waves only (rank arithmetic stays shifts).
-                const int rounds = (total_items + per_round - 1) >> (6 - gshift);
+                const int rounds = (total_items * n1w + 63) >> 6;                 // >= ceil(items / per_round) - 1
                 if (a.compact && nactive == 64 && rounds * 155 + 100 < 170 * n1w) {
                     const int lane64 = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32),
                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0));
@@ -543,7 +544,7 @@ sat_sa_kernel(const SatKernelArgs a)
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     // active-lane rank -> (item of the round, map word)
-                    const int sub = lane64 >> gshift, kw = lane64 & ((1 << gshift) - 1);
+                    const int sub = __mul24(lane64, recip) >> 16, kw = lane64 - __mul24(sub, n1w);
                     for (int base = 0; base < total_items; base += per_round) {
                         const int idx = base + sub;
                         if (sub < per_round && idx < total_items && kw < n1w) {
