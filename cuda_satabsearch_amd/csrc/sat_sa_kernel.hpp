@@ -276,7 +276,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
     size_t bytes = dcells * 8;
     if (q_in_lds) bytes += n1w * (size_t)n1p * 20;            // float4 + code dword per (group, column)
-    bytes += n1w * chains * 4 * (lsoln ? 2 : 1);
+    bytes += n1w * (chains + 1) * 4 * (lsoln ? 2 : 1);       // map words, row stride chains + 1 (bank skew)
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
     bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
@@ -322,8 +322,12 @@ sat_sa_kernel(const SatKernelArgs a)
     float4 *qdistL = reinterpret_cast<float4 *>(Dc + dcells);
     uint32_t *qcodeL = reinterpret_cast<uint32_t *>(qdistL + (QLDS ? (size_t)n1w * N1P : 0));
     uint32_t *smap = qcodeL + (QLDS ? (size_t)n1w * N1P : 0);
-    uint32_t *bmap = smap + (size_t)n1w * T;
-    uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * T : 0);
+    // map word w of chain c lives at w*TP + c with TP = T + 1: the odd stride puts the words of
+    // one chain in different banks (the compacted loop reads them from n1w lanes at once) and
+    // keeps word w of all chains contiguous for the static loops
+    const int TP = T + 1;
+    uint32_t *bmap = smap + (size_t)n1w * TP;
+    uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * TP : 0);
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
     unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
     // explicit LDS address space: these two are written by some lanes and read by others of the
@@ -397,7 +401,7 @@ sat_sa_kernel(const SatKernelArgs a)
     uint8_t *smap_b = reinterpret_cast<uint8_t *>(smap);
     uint8_t *bmap_b = reinterpret_cast<uint8_t *>(bmap);
     // byte k of this lane's map lives at ((k>>2)*T + tid)*4 + (k&3)
-    const int T4 = T << 2, tid4 = tid << 2;
+    const int T4 = TP << 2, tid4 = tid << 2;
     auto map_byte_addr = [&](int k) -> int { return __mul24(k >> 2, T4) + tid4 + (k & 3); };
 
     const uint64_t subseq_lo = (uint64_t)a.ordinal[e];
@@ -414,7 +418,7 @@ sat_sa_kernel(const SatKernelArgs a)
         Bits<M2W> occ = bits_zero<M2W>();
         {
             const uint32_t nullword = (uint32_t)NULLJ * 0x01010101u;
-            for (int w = 0; w < n1w; w++) smap[w * T + tid] = nullword;
+            for (int w = 0; w < n1w; w++) smap[w * TP + tid] = nullword;
             int j = 0;
             bool stopped = false;
             for (int i0 = 0; i0 < n1; i0 += 4) {
@@ -455,7 +459,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 const int below = i + 1 - 4 * kw;
                 const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
                 const uint32_t qi = (uint32_t)(kw * N1P + i);
-                score = quad_terms(load_qdist(qi), load_qcode(qi), drow, smap[kw * T + tid], force, score);
+                score = quad_terms(load_qdist(qi), load_qcode(qi), drow, smap[kw * TP + tid], force, score);
             };
             // one lane per chain: the group index stays in scalar registers
             if (lpc == 1) for (int kw = (i + 1) >> 2; kw < n1w; kw++) row_group(kw);
@@ -467,7 +471,7 @@ sat_sa_kernel(const SatKernelArgs a)
             best = score;
             best_restart = (uint32_t)restart;
             if (lsoln)
-                for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * T + tid];
+                for (int w = 0; w < n1w; w++) bmap[w * TP + tid] = smap[w * TP + tid];
         }
 
         // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
@@ -550,7 +554,7 @@ sat_sa_kernel(const SatKernelArgs a)
                         if (sub < per_round && idx < total_items && kw < n1w) {
                             const uint32_t it = items[idx];
                             const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
-                            const uint32_t word = smap[kw * T + owner];
+                            const uint32_t word = smap[kw * TP + owner];
                             const uint32_t qi = (uint32_t)(kw * N1P + si);
                             const int v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
                             __hip_atomic_fetch_add(acc + owner, (it >> 24) ? -v : v,
@@ -567,7 +571,7 @@ sat_sa_kernel(const SatKernelArgs a)
                     const uint2 *nrow = Dc + __mul24(newj, n2p);
                     int sum_new = 0, sum_old = 0;
                     auto move_group = [&](int kw) {
-                        const uint32_t word = smap[kw * T + tid];
+                        const uint32_t word = smap[kw * TP + tid];
                         const uint32_t qi = (uint32_t)(kw * N1P + ssei);      // 32-bit offset from a uniform base
                         const float4 qd = load_qdist(qi);
                         const uint32_t qc = load_qcode(qi);
@@ -588,7 +592,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 best = newscore;
                 best_restart = (uint32_t)restart;
                 if (lsoln) {
-                    for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * T + tid];
+                    for (int w = 0; w < n1w; w++) bmap[w * TP + tid] = smap[w * TP + tid];
                     bmap_b[map_byte_addr(ssei)] = (uint8_t)newj;
                 }
             }
