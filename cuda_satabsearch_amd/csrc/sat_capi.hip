@@ -262,7 +262,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || n1p < 32;
             size_t lds = 0;
             for (;;) {
-                lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains * 4, lsoln != 0, qlds, compact);   // room for 4 lanes per chain
+                lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains, lsoln != 0, qlds, compact);
                 if (lds <= kLdsLimit) break;
                 if (chains > 64) { chains -= 64; continue; }
                 if (qlds) {                                    // query cells stay in L1/L2 instead
@@ -285,6 +285,11 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                     int v = atoi(ov);
                     if (v >= 0 && v <= 2 && (chains << v) <= 1024) lpc_shift = v;
                 }
+            }
+            // the per-wave tables grow with the lanes: re-size, backing off if that no longer fits
+            for (;; lpc_shift--) {
+                lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains << lpc_shift, lsoln != 0, qlds, compact);
+                if (lds <= kLdsLimit || lpc_shift == 0) break;
             }
             const int threads = chains << lpc_shift;
             a.lpc_shift = lpc_shift;

@@ -281,7 +281,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
     bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
     if (compact) {
-        bytes += (size_t)((threads + 63) / 64) * 128 * 4;     // per-wave item table (<= 2 rows per lane)
+        bytes += (size_t)((threads + 63) / 64) * 64 * 4;      // per-wave item table (compaction handles <= 64 rows)
         bytes += (size_t)chains * 4;                          // per-chain delta accumulator
     }
     return bytes;
@@ -335,8 +335,8 @@ sat_sa_kernel(const SatKernelArgs a)
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     typedef __attribute__((address_space(3))) int32_t lds_i32_t;
     const uint32_t items_off = (uint32_t)(reinterpret_cast<unsigned char *>(red + 16) - lds_raw);
-    lds_u32_t *items = (lds_u32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)(lane_id >> 6) * 512u);
-    lds_i32_t *acc = (lds_i32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)((nthreads + 63) >> 6) * 512u);
+    lds_u32_t *items = (lds_u32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)(lane_id >> 6) * 256u);
+    lds_i32_t *acc = (lds_i32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)((nthreads + 63) >> 6) * 256u);
     // query group (4 distances, 4 code bytes) of column `col`: from LDS, or from global memory
     // through L1 - the descriptor's pointers are cast to the global address space so that the
     // loads are global_load (a pointer read from memory is otherwise a generic "flat" pointer)
@@ -533,7 +533,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 // ~155 and its set-up ~100; the static loops cost ~85 per (row, word) = 170 per word.
                 // Full waves only (rank arithmetic stays shifts).
                 const int rounds = (total_items * n1w + 63) >> 6;                 // >= ceil(items / per_round) - 1
-                if (a.compact && nactive == 64 && rounds * 155 + 100 < 170 * n1w) {
+                if (a.compact && nactive == 64 && total_items <= 64 && rounds * 155 + 100 < 170 * n1w) {
                     const int lane64 = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32),
                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0));
                     const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0)) +
