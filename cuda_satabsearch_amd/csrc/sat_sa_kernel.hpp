@@ -549,6 +549,7 @@ sat_sa_kernel(const SatKernelArgs a)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     // active-lane rank -> (item of the round, map word)
                     const int sub = __mul24(lane64, recip) >> 16, kw = lane64 - __mul24(sub, n1w);
+                    const bool quads = (n1w & 3) == 0;
                     for (int base = 0; base < total_items; base += per_round) {
                         const int idx = base + sub;
                         if (sub < per_round && idx < total_items && kw < n1w) {
@@ -556,9 +557,18 @@ sat_sa_kernel(const SatKernelArgs a)
                             const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
                             const uint32_t word = smap[kw * TP + owner];
                             const uint32_t qi = (uint32_t)(kw * N1P + si);
-                            const int v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
-                            __hip_atomic_fetch_add(acc + owner, (it >> 24) ? -v : v,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            int v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
+                            v = (it >> 24) ? -v : v;
+                            if (quads) {
+                                // items are aligned groups of n1w = 4m lanes: add up each quad of lanes with
+                                // two DPP moves, so that a quarter of the lanes hit the owner's accumulator
+                                v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                                v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+                                if ((kw & 3) == 0)
+                                    __hip_atomic_fetch_add(acc + owner, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            } else {
+                                __hip_atomic_fetch_add(acc + owner, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
