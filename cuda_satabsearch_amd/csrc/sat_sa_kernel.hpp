@@ -511,7 +511,21 @@ sat_sa_kernel(const SatKernelArgs a)
             // Branch-free: in a 64-lane wave every case occurs anyway.
             const int cnt = bits_count<M2W>(cand);
             const int pick = cnt > 1 ? scaled_index(to_uniform(r.y), cnt) : 0;
-            const int sel = bits_select<M2W>(cand, pick);
+            int sel;
+            if (M2W == 1 && a.lorder) {
+                // inside an order window the picked rank is small (few free same-type SSEs): strip
+                // the lowest set bit `pick` times, looping while any lane of the wave still has to
+                uint32_t c = cand.w[0];
+                int left = pick;
+                while (__any(left > 0)) {
+                    const bool go = left > 0;
+                    c = go ? (c & (c - 1u)) : c;
+                    left -= go ? 1 : 0;
+                }
+                sel = __ffs(c) - 1;
+            } else {
+                sel = bits_select<M2W>(cand, pick);
+            }
             const int newj = cnt == 0 ? NULLJ : sel;
 
             // score change (deltasd, K.cu:502-535)
