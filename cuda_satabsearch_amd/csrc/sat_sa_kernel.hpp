@@ -248,11 +248,6 @@ __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, co
 // key = seed_q, counter = (block, 0, subsequence lo, subsequence hi).
 __device__ __forceinline__ uint4 philox_block(uint64_t seed_q, uint64_t subsequence, uint32_t block)
 {
-#ifdef SAT_ABL_NO_PHILOX   // timing-only ablation (scripts/exp): a 3-op hash instead of 10 Philox rounds
-    uint32_t h = (uint32_t)(subsequence >> 32) * 0x9E3779B9u + block * 0x85EBCA6Bu + (uint32_t)subsequence;
-    h ^= h >> 15;
-    return uint4{ h * 0x2C1B3C6Du, h * 0x297A2D39u, (h ^ 0x5bd1e995u) * 0x7FEB352Du, h };
-#endif
     rocrand_state_philox4x32_10 st;
     rocrand_init(seed_q, subsequence, 4ull * block, &st);
     return rocrand4(&st);
