@@ -12,7 +12,9 @@
  * device memory.  Threading: one context per host thread; no globals.
  * Errors: every int-returning call yields 0 on success and a negative SAT_E*
  * code otherwise; sat_last_error() has the text.  Nothing in the library calls
- * exit() or abort().  There is no CPU fallback: without a usable HIP device
+ * exit() or abort().  Environment (tuning / test overrides of launch heuristics, results do
+ * not depend on them): SAT_EXP_LPC = 0|1|2 (log2 lanes per chain), SAT_EXP_COMPACT = 0|1
+ * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS).  There is no CPU fallback: without a usable HIP device
  * sat_ctx_create() fails with SAT_ENODEVICE.
  */
 #ifndef SATABSEARCH_H

@@ -115,6 +115,25 @@ def test_large_everything_lds_spill_regime(searcher):
     check(searcher, db, q, True, True, 256)
 
 
+# ---------------------------------------------------------------- every execution mode
+@pytest.mark.parametrize("env", [{"SAT_EXP_LPC": "0", "SAT_EXP_COMPACT": "0"}, {"SAT_EXP_LPC": "0", "SAT_EXP_COMPACT": "1"},
+                                 {"SAT_EXP_LPC": "1", "SAT_EXP_COMPACT": "1"}, {"SAT_EXP_LPC": "2", "SAT_EXP_COMPACT": "1"},
+                                 {"SAT_EXP_LPC": "2", "SAT_EXP_COMPACT": "0"}, {"SAT_EXP_QLDS": "1"}],
+                         ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
+def test_forced_execution_modes(searcher, monkeypatch, env):
+    """The launch heuristics (lanes per chain, work compaction, query cells in LDS) only change
+    how the work is laid out; forced through the library's tuning overrides, every layout must
+    give the oracle's bits, for both LORDER modes and with solution maps."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    db = sat.synth.make_db(150, 6, 40, seed=21)
+    searcher.upload(db)
+    for src, keep in ((140, 0.8), (20, 1.0)):
+        q = sat.synth.planted_query(db, src, keep=keep)
+        check(searcher, db, q, True, True, 128)
+        check(searcher, db, q, False, True, 100)
+
+
 # ---------------------------------------------------------------- keys of the streams
 def test_sharding_does_not_change_results(searcher):
     db = sat.synth.make_db(600, 8, 32)
