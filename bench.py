@@ -180,10 +180,19 @@ def main():
         achieved = abytes / (kavg_ms * 1e-3) / 1e9
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (profiles/)
         traffic = None
+        issue = None
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "bench_traffic.json")))
             if t.get("entries_per_launch") == n_local:
                 traffic = t["hbm_bytes_per_launch"]
+                if t.get("valu_wave_instr_per_launch"):
+                    # what actually binds: VALU issue.  1024 SIMDs x one wave64 instr per 2 clk at 2.4 GHz
+                    rate = t["valu_wave_instr_per_launch"] / (kavg_ms * 1e-3)
+                    issue = {"bound": "valu_issue", "achieved": rate, "peak": 1024 * 2.4e9 / 2, "unit": "wave-instr/s",
+                             "frac": rate / (1024 * 2.4e9 / 2), "lds_busy_frac": t.get("lds_busy_frac"),
+                             "note": "VALU wave-instructions per launch from the committed rocprofv3 PMC pass / live kernel time; "
+                                     "the mix is ~55 % half-rate opcodes (profiles/r01_gfx950_valu_opcode_cost.txt), so ~0.65 "
+                                     "of this nominal peak is the practical ceiling"}
         except (OSError, ValueError, KeyError):
             pass
         metric = "db-structure scorings/sec (query\u00d7db pairs/sec) at r=128; 1/2/4/8 MI355X"
@@ -216,6 +225,8 @@ def main():
                          "note": "nominal bound only: 2648 B per scoring against 12 800 dependent SA steps; "
                                  "the kernel is VALU/LDS-issue bound (DESIGN.md section 4)"},
         }
+        if issue:
+            out["binding_resource"] = issue
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(db, (qt, qd, qtypes))
         print(json.dumps(out), flush=True)

@@ -56,6 +56,9 @@ if "FETCH_SIZE" in vals:
     json.dump({"source": name + "_summary.txt", "entries_per_launch": int(vals["meta"]["Grid_Size"]) // int(vals["meta"]["Workgroup_Size"]) if "meta" in vals else None,
                "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals.get("WRITE_SIZE", 0.0),
                "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals.get("WRITE_SIZE", 0.0) * 1024,
+               "valu_wave_instr_per_launch": vals.get("SQ_INSTS_VALU"), "lds_wave_instr_per_launch": vals.get("SQ_INSTS_LDS"),
+               "kernel_ms_profiled": (kern_ns / 1e6) if kern_ns else None,
+               "lds_busy_frac": (vals["SQ_LDS_IDX_ACTIVE"] / 256 / (vals["GRBM_GUI_ACTIVE"] / 8)) if "SQ_LDS_IDX_ACTIVE" in vals and "GRBM_GUI_ACTIVE" in vals else None,
                "note": "FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE x 1024; separate --pmc passes"},
               open(os.path.join(dst, "bench_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, name + "_summary.txt"), "w").write("\n".join(lines) + "\n")
