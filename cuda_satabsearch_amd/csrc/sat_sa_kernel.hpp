@@ -277,7 +277,6 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
     if (compact) {
         bytes += (size_t)((threads + 63) / 64) * 64 * 4;      // per-wave item table (compaction handles <= 64 rows)
-        bytes += (size_t)chains * 4;                          // per-chain delta accumulator
     }
     return bytes;
 }
@@ -331,7 +330,6 @@ sat_sa_kernel(const SatKernelArgs a)
     typedef __attribute__((address_space(3))) int32_t lds_i32_t;
     const uint32_t items_off = (uint32_t)(reinterpret_cast<unsigned char *>(red + 16) - lds_raw);
     lds_u32_t *items = (lds_u32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)(lane_id >> 6) * 256u);
-    lds_i32_t *acc = (lds_i32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)((nthreads + 63) >> 6) * 256u);
     // query group (4 distances, 4 code bytes) of column `col`: from LDS, or from global memory
     // through L1 - the descriptor's pointers are cast to the global address space so that the
     // loads are global_load (a pointer read from memory is otherwise a generic "flat" pointer)
@@ -547,12 +545,14 @@ sat_sa_kernel(const SatKernelArgs a)
                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0));
                     const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0)) +
                                     __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
-                    if (part == 0) acc[tid] = 0;
-                    // item = row | moved SSE << 8 | owner chain << 16 | negate << 24
-                    if (nitems >= 1)
-                        items[pre] = (uint32_t)(oreal ? oldj : newj) | ((uint32_t)ssei << 8) | ((uint32_t)tid << 16) |
-                                     (oreal ? 1u << 24 : 0u);
-                    if (nitems == 2) items[pre + 1] = (uint32_t)newj | ((uint32_t)ssei << 8) | ((uint32_t)tid << 16);
+                    // item = row | moved SSE << 8 | owner chain << 16 | negate << 24.  The slot doubles as
+                    // the row's accumulator: the lanes that serve an item all read it in one instruction,
+                    // then add their signed sums to it; the owner subtracts what it wrote.
+                    const uint32_t item1 = (uint32_t)(oreal ? oldj : newj) | ((uint32_t)ssei << 8) | ((uint32_t)tid << 16) |
+                                           (oreal ? 1u << 24 : 0u);
+                    const uint32_t item2 = (uint32_t)newj | ((uint32_t)ssei << 8) | ((uint32_t)tid << 16);
+                    if (nitems >= 1) items[pre] = item1;
+                    if (nitems == 2) items[pre + 1] = item2;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -564,6 +564,7 @@ sat_sa_kernel(const SatKernelArgs a)
                         if (sub < per_round && idx < total_items && kw < n1w) {
                             const uint32_t it = items[idx];
                             const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
+                            lds_i32_t *slot = (lds_i32_t *)(items + idx);
                             const uint32_t word = smap[kw * TP + owner];
                             const uint32_t qi = (uint32_t)(kw * N1P + si);
                             int v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
@@ -574,16 +575,20 @@ sat_sa_kernel(const SatKernelArgs a)
                                 v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
                                 v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
                                 if ((kw & 3) == 0)
-                                    __hip_atomic_fetch_add(acc + owner, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                    __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             } else {
-                                __hip_atomic_fetch_add(acc + owner, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    delta = total_items ? acc[tid] : 0;
+                    delta = 0;
+                    if (nitems >= 1) delta = (int)(items[pre] - item1);
+                    if (nitems == 2) delta += (int)(items[pre + 1] - item2);
+                    // with several lanes per chain only part 0 listed rows: hand its sum to the others
+                    if (lpc > 1) delta = __shfl(delta, (lane_id & 63) & ~(lpc - 1), 64);
                 } else {
                     // dense regime: every lane scores its own two rows
                     const uint2 *orow = Dc + __mul24(oldj, n2p);
