@@ -82,6 +82,33 @@ def cpu_baseline(db, q, sample_seconds=15.0):
             "sample": sample + " (oracle/sa_oracle.c, gcc -O3)"}
 
 
+def cpu_baseline_all_cores(db, q, seconds=8.0):
+    """Throughput of the oracle port on every host core of this box: one thread per contiguous
+    chunk of a bounded prefix, each with its own drand48 stream (ctypes releases the GIL).  Not
+    byte-comparable to `-c` (neither is any parallel run); the single-thread figure above is."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    qt, qd, qtypes = q
+    # one GPU's share of the host on the bench boxes is 16 cores, whatever cpu_count() says
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    t0 = time.time()
+    oracle_lib.search(db, qt, qd, qtypes, True, False, MAXSTART, mode=oracle_lib.RNG_DRAND48, entries=np.arange(32))
+    per_entry = (time.time() - t0) / 32
+    per_core = int(max(32, min(len(db) // cores, seconds / max(per_entry, 1e-6))))
+    chunks = [np.arange(c * per_core, (c + 1) * per_core) for c in range(cores)]
+
+    def work(c):
+        oracle_lib.search(db, qt, qd, qtypes, True, False, MAXSTART, mode=oracle_lib.RNG_DRAND48, entries=chunks[c],
+                          lcg=oracle_lib.lib().sa_oracle_srand48(1234 + c))
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    dt = time.time() - t0
+    return {"value": cores * per_core / dt, "unit": "db-structure scorings/sec", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {per_core} entries of the rank-0 shard, same query, r={MAXSTART}, one drand48 stream per thread"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +256,7 @@ def main():
             out["binding_resource"] = issue
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(db, (qt, qd, qtypes))
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(db, (qt, qd, qtypes))
         print(json.dumps(out), flush=True)
 
     if world > 1:
