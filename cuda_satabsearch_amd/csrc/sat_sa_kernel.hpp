@@ -20,10 +20,11 @@
 //        (same for all lanes): 16-byte and 4-byte loads from consecutive addresses.
 //        Diagonal and padding distances are the sentinel +1e30, which removes the k == i
 //        term (K.cu:524,530).  Read through L1/L2 (32+-SSE queries) or staged in LDS.
-//   smap (LDS) per-lane SSE map, one byte per query SSE, stored word-interleaved
-//        smap[w*T + tid]: word w of every lane is contiguous, so the uniform-k loop
-//        reads it conflict free and a lane's random byte access always lands in bank
-//        (tid mod 32) - also conflict free.
+//   smap (LDS) per-chain SSE map, one byte per query SSE, stored word-interleaved
+//        smap[w*(T+1) + chain]: word w of every chain is contiguous, so a loop over a
+//        uniform word reads it conflict free; the odd row stride T+1 spreads the words of
+//        ONE chain over different banks for the compacted loop, where the lanes serving
+//        an item read that chain's n1w words in one instruction.
 //   bmap same layout, best map so far (LSOLN only).
 //
 // Work compaction in the SA step (the db-scan regime is sparse: on random pairs ~25 % of
