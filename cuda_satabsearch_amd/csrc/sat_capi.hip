@@ -225,6 +225,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     a.maxstart = maxstart;
     a.ptab = ctx->d_ptab;
     a.prow = ctx->d_prow;
+    a.bmap_slabs = nullptr;
+    a.bmap_slab_words = 0;
 
     for (int c = 0; c < 4; c++) {
         const int nqc = ctx->class_begin[c + 1] - ctx->class_begin[c];
@@ -299,13 +301,42 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
             a.entry_list = ctx->d_lists + (one_launch ? 0 : ctx->bucket_begin[b]);
-            // grid.y is limited to 65535: split very long query lists
+            // LSOLN: every workgroup of a launch owns a slab of best maps in global memory; launches
+            // are cut so that the slabs stay under 1 GiB (they are reused launch after launch on the
+            // same stream).  grid.y is limited to 65535: very long query lists are split too.
+            const size_t slab_words = lsoln ? (size_t)((n1max + 3) / 4) * chains : 0;
+            int max_entries = count;
+            if (lsoln) {
+                const size_t budget_words = ((size_t)1 << 30) / 4;
+                size_t per_query_col = slab_words;                 // one workgroup
+                size_t fit = budget_words / per_query_col;         // workgroups per launch
+                if (fit < 1) fit = 1;
+                const int qn_cap = nqc < 65535 ? nqc : 65535;
+                max_entries = (int)(fit / (size_t)qn_cap);
+                if (max_entries < 1) max_entries = 1;
+                if (max_entries > count) max_entries = count;
+            }
             for (int q0 = 0; q0 < nqc; q0 += 65535) {
-                SatKernelArgs part = a;
-                part.queries = a.queries + q0;
                 const int qn = nqc - q0 < 65535 ? nqc - q0 : 65535;
-                hipLaunchKernelGGL(fn, dim3(count, qn), dim3(threads), lds, stream, part);
-                HIP_TRY(hipGetLastError());
+                for (int e0 = 0; e0 < count; e0 += max_entries) {
+                    const int en = count - e0 < max_entries ? count - e0 : max_entries;
+                    SatKernelArgs part = a;
+                    part.queries = a.queries + q0;
+                    part.entry_list = a.entry_list + e0;
+                    if (lsoln) {
+                        const size_t need = slab_words * (size_t)en * qn;
+                        if (need > ctx->bmap_slabs_cap) {
+                            HIP_TRY(hipStreamSynchronize(stream));
+                            dev_free(ctx->d_bmap_slabs);
+                            HIP_TRY(hipMalloc(&ctx->d_bmap_slabs, need * sizeof(uint32_t)));
+                            ctx->bmap_slabs_cap = need;
+                        }
+                        part.bmap_slabs = ctx->d_bmap_slabs;
+                        part.bmap_slab_words = (uint32_t)slab_words;
+                    }
+                    hipLaunchKernelGGL(fn, dim3(en, qn), dim3(threads), lds, stream, part);
+                    HIP_TRY(hipGetLastError());
+                }
             }
         }
     }
@@ -368,6 +399,7 @@ void sat_ctx_destroy(sat_ctx *ctx)
     free_db(ctx);
     dev_free(ctx->d_qblob);
     dev_free(ctx->d_qdesc);
+    dev_free(ctx->d_bmap_slabs);
     dev_free(ctx->d_ptab);
     dev_free(ctx->d_prow);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -49,6 +49,8 @@ struct sat_ctx {
     size_t scores_cap = 0;
     int8_t *d_ssemaps = nullptr;
     size_t ssemaps_cap = 0;
+    uint32_t *d_bmap_slabs = nullptr;        // LSOLN scratch: one best-map slab per workgroup of a launch
+    size_t bmap_slabs_cap = 0;               // in 32-bit words
 };
 
 

@@ -25,7 +25,10 @@
 //        uniform word reads it conflict free; the odd row stride T+1 spreads the words of
 //        ONE chain over different banks for the compacted loop, where the lanes serving
 //        an item read that chain's n1w words in one instruction.
-//   bmap same layout, best map so far (LSOLN only).
+//   bmap (LSOLN only) best map so far of every chain, same word-interleaved layout but in
+//        GLOBAL memory (one slab per workgroup of the launch): it is written on improvements
+//        only and read once by the winner, the resident slabs (~4 KB x a few thousand
+//        workgroups) live in L2, and keeping it out of LDS keeps 12 workgroups per CU.
 //
 // Work compaction in the SA step (the db-scan regime is sparse: on random pairs ~25 % of
 // the query SSEs are matched, the moved SSE has a real old image in 25 % and a real new
@@ -110,6 +113,8 @@ struct SatKernelArgs {
     int32_t         lorder, lsoln, maxstart;
     int32_t         lpc_shift;    // log2(lanes per chain): 0, 1 or 2
     int32_t         compact;      // 1: the SA step may use the wave-level work compaction (its LDS tables exist)
+    uint32_t       *bmap_slabs;   // LSOLN: best-map slab of workgroup g at g * bmap_slab_words
+    uint32_t        bmap_slab_words;
     // Metropolis table
     const float    *ptab;         // ragged rows
     const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
@@ -272,7 +277,8 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
     size_t bytes = dcells * 8;
     if (q_in_lds) bytes += n1w * (size_t)n1p * 20;            // float4 + code dword per (group, column)
-    bytes += n1w * (chains + 1) * 4 * (lsoln ? 2 : 1);       // map words, row stride chains + 1 (bank skew)
+    bytes += n1w * (chains + 1) * 4;                          // map words, row stride chains + 1 (bank skew)
+    (void)lsoln;                                              // the best maps live in global memory
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
     bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
@@ -321,8 +327,9 @@ sat_sa_kernel(const SatKernelArgs a)
     // one chain in different banks (the compacted loop reads them from n1w lanes at once) and
     // keeps word w of all chains contiguous for the static loops
     const int TP = T + 1;
-    uint32_t *bmap = smap + (size_t)n1w * TP;
-    uint32_t *tmask = bmap + (lsoln ? (size_t)n1w * TP : 0);
+    uint32_t *tmask = smap + (size_t)n1w * TP;
+    // best maps: word w of chain c at w*T + c of this workgroup's slab (global memory)
+    uint32_t *bmap = lsoln ? a.bmap_slabs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.bmap_slab_words : nullptr;
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
     unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
     // explicit LDS address space: these two are written by some lanes and read by others of the
@@ -394,6 +401,7 @@ sat_sa_kernel(const SatKernelArgs a)
 
     uint8_t *smap_b = reinterpret_cast<uint8_t *>(smap);
     uint8_t *bmap_b = reinterpret_cast<uint8_t *>(bmap);
+    auto bmap_byte_addr = [&](int k) -> int { return (__mul24(k >> 2, T) + tid) * 4 + (k & 3); };
     // byte k of this lane's map lives at ((k>>2)*T + tid)*4 + (k&3)
     const int T4 = TP << 2, tid4 = tid << 2;
     auto map_byte_addr = [&](int k) -> int { return __mul24(k >> 2, T4) + tid4 + (k & 3); };
@@ -465,7 +473,7 @@ sat_sa_kernel(const SatKernelArgs a)
             best = score;
             best_restart = (uint32_t)restart;
             if (lsoln)
-                for (int w = 0; w < n1w; w++) bmap[w * TP + tid] = smap[w * TP + tid];
+                for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
         }
 
         // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
@@ -617,8 +625,8 @@ sat_sa_kernel(const SatKernelArgs a)
                 best = newscore;
                 best_restart = (uint32_t)restart;
                 if (lsoln) {
-                    for (int w = 0; w < n1w; w++) bmap[w * TP + tid] = smap[w * TP + tid];
-                    bmap_b[map_byte_addr(ssei)] = (uint8_t)newj;
+                    for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
+                    bmap_b[bmap_byte_addr(ssei)] = (uint8_t)newj;
                 }
             }
 
@@ -682,7 +690,7 @@ sat_sa_kernel(const SatKernelArgs a)
         ((((unsigned long long)(uint32_t)(best + 0x40000000)) << 32) | (0xFFFFFFFFu - best_restart)) == win) {
         int8_t *out = Q.ssemaps + (size_t)e * n1;
         for (int i = 0; i < n1; i++) {
-            int j = bmap_b[map_byte_addr(i)];
+            int j = bmap_b[bmap_byte_addr(i)];
             out[i] = (int8_t)(j == NULLJ ? -1 : j);
         }
     }
