@@ -89,7 +89,8 @@ int build_metropolis_table(sat_ctx *ctx)
         }
         rows[2 * it] = (int32_t)tab.size();
         rows[2 * it + 1] = last;
-        tab.insert(tab.end(), row.begin(), row.begin() + last + 1);
+        // stored times 2^32 (exact): the kernel compares with 2^32 * u
+        for (int nd = 0; nd <= last; nd++) tab.push_back(ldexpf(row[nd], 32));
         tab.push_back(0.0f);                         // entry last + 1: "can never be accepted"
         temp = temp * 0.95f;
     }
@@ -227,6 +228,12 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     a.prow = ctx->d_prow;
     a.bmap_slabs = nullptr;
     a.bmap_slab_words = 0;
+#ifdef SAT_PHASE_TIMING
+    static unsigned long long *d_phase = nullptr;
+    if (!d_phase) HIP_TRY(hipMalloc(&d_phase, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_phase, 0, 8 * sizeof(unsigned long long), stream));
+    a.phase = d_phase;
+#endif
 
     for (int c = 0; c < 4; c++) {
         const int nqc = ctx->class_begin[c + 1] - ctx->class_begin[c];
@@ -294,6 +301,11 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                 if (lds <= kLdsLimit || lpc_shift == 0) break;
             }
             const int threads = chains << lpc_shift;
+            // experiment knob: extra (unused) LDS bytes per workgroup, to lower the occupancy
+            if (const char *ov = getenv("SAT_EXP_LDS_PAD")) {
+                const size_t pad = (size_t)atoi(ov);
+                if (lds + pad <= kLdsLimit) lds += pad;
+            }
             a.lpc_shift = lpc_shift;
             a.compact = compact ? 1 : 0;
             kernel_fn fn = pick_kernel(n1p, m2w, qlds);
@@ -340,6 +352,19 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             }
         }
     }
+#ifdef SAT_PHASE_TIMING
+    {
+        unsigned long long h[8];
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h, d_phase, sizeof h, hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) tot += h[k];
+        static const char *nm[8] = { "draw+proposal", "compaction set-up", "compacted rounds", "read-back/static loops",
+                                     "best tracking", "metropolis+update", "thinit+full score", "restart loop" };
+        for (int k = 0; k < 8; k++)
+            fprintf(stderr, "phase %-24s %14llu wave-cycles %5.1f%%\n", nm[k], h[k], tot ? 100.0 * h[k] / tot : 0.0);
+    }
+#endif
     return SAT_OK;
 }
 

@@ -116,8 +116,11 @@ struct SatKernelArgs {
     uint32_t       *bmap_slabs;   // LSOLN: best-map slab of workgroup g at g * bmap_slab_words
     uint32_t        bmap_slab_words;
     // Metropolis table
-    const float    *ptab;         // ragged rows
+    const float    *ptab;         // ragged rows of 2^32 * expf(-nd / temp)
     const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
+#ifdef SAT_PHASE_TIMING
+    unsigned long long *phase;    // [8] wave-cycles per SA-step phase (diagnostic builds only, scripts/exp/variant_lib.sh)
+#endif
 };
 
 namespace satk {
@@ -254,18 +257,49 @@ __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, co
 // key = seed_q, counter = (block, 0, subsequence lo, subsequence hi).
 __device__ __forceinline__ uint4 philox_block(uint64_t seed_q, uint64_t subsequence, uint32_t block)
 {
-    rocrand_state_philox4x32_10 st;
-    rocrand_init(seed_q, subsequence, 4ull * block, &st);
-    return rocrand4(&st);
+    // Philox4x32-10 written out (same words as rocrand_init(seed_q, subsequence, 4 * block) +
+    // rocrand4, which tests/ check through the oracle): in every use here the block and the low
+    // subsequence word are wave-uniform, so rounds 1-3 are left to the compiler (it keeps the
+    // uniform half on the scalar unit); from round 4 on all four words are per lane and the two
+    // three-way XORs of a round are one v_bitop3_b32 each.
+    uint32_t c0 = block, c1 = 0u, c2 = (uint32_t)subsequence, c3 = (uint32_t)(subsequence >> 32);
+    uint32_t k0 = (uint32_t)seed_q, k1 = (uint32_t)(seed_q >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0, n2;
+        if (r < 3) {
+            n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+            n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        } else {
+            n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+            n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        }
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return uint4{ c0, c1, c2, c3 };
+}
+// 2^32 * (uniform draw of word v): rocRAND's uniform_distribution is 2^-32 + float(v) * 2^-32
+// in (0, 1] (rocrand_uniform.h:65-68); scaling by a power of two is exact, so float(v) + 1.0f is
+// that value times 2^32 with the same two roundings.
+__device__ __forceinline__ float draw32(uint32_t v)
+{
+    return (float)v + 1.0f;
 }
 __device__ __forceinline__ float to_uniform(uint32_t v)
 {
-    return rocrand_device::detail::uniform_distribution(v);   // (0, 1], rocrand_uniform.h:65-68
+    return draw32(v) * 2.3283064365386963e-10f;
 }
-// (int)((u - EPS) * n) evaluated in double, as K.cu:1042 and K.cu:710 do
-__device__ __forceinline__ int scaled_index(float u, int n)
+// (int)((u - EPS) * n) evaluated in double, as K.cu:1042 and K.cu:710 do, from w = 2^32 * u:
+// w * 2^-32 is exact in double, so the fused multiply-add rounds once, where u - EPS rounds.
+__device__ __forceinline__ int scaled_index(float w, double n)
 {
-    return (int)(((double)u - SAT_K_EPS) * (double)n);
+    return (int)(__builtin_fma((double)w, 2.3283064365386963e-10, -SAT_K_EPS) * n);
 }
 
 // LDS byte size of one workgroup
@@ -288,12 +322,53 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     return bytes;
 }
 
+#ifdef SAT_EXP_PERTURB
+// Diagnostic builds only (scripts/exp/variant_lib.sh): extra instructions of one kind per SA step, to see
+// which issue resource the step loop is sensitive to.  1: 40 full-rate VALU, 2: 40 SALU, 3: 10 LDS
+// reads + wait, 4: 40 s_nop, 5: 40 half-rate VALU.
+#define SAT_R10(x) x x x x x x x x x x
+__device__ __forceinline__ void perturb(uint32_t (&d)[4])
+{
+#if SAT_EXP_PERTURB == 1
+    asm volatile(SAT_R10("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n")
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+#elif SAT_EXP_PERTURB == 2
+    uint32_t s0 = __builtin_amdgcn_readfirstlane(d[1]), s1 = __builtin_amdgcn_readfirstlane(d[2]);
+    asm volatile(SAT_R10("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %0, %0, 3\n s_add_u32 %1, %1, 3\n")
+                 : "+s"(s0), "+s"(s1) : : "scc");
+    d[1] = s0; d[2] = s1;
+#elif SAT_EXP_PERTURB == 3
+    uint32_t addr = (threadIdx.x & 63u) << 2, t0, t1;
+    asm volatile("ds_read_b32 %0, %2\n ds_read_b32 %1, %2 offset:256\n ds_read_b32 %0, %2 offset:512\n ds_read_b32 %1, %2 offset:768\n"
+                 "ds_read_b32 %0, %2 offset:1024\n ds_read_b32 %1, %2 offset:1280\n ds_read_b32 %0, %2 offset:1536\n"
+                 "ds_read_b32 %1, %2 offset:1792\n ds_read_b32 %0, %2 offset:2048\n ds_read_b32 %1, %2 offset:2304\n s_waitcnt lgkmcnt(0)\n"
+                 : "=&v"(t0), "=&v"(t1) : "v"(addr) : "memory");
+    d[0] ^= t0 & t1 & 0x80000000u;
+#elif SAT_EXP_PERTURB == 4
+    asm volatile(SAT_R10("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"));
+#elif SAT_EXP_PERTURB == 5
+    asm volatile(SAT_R10("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n")
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+#endif
+}
+#endif
+
 }  // namespace satk
+
+#ifdef SAT_PHASE_TIMING
+#define SAT_PHASE_INIT unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t0 = __builtin_amdgcn_s_memtime()
+#define SAT_PHASE(k) do { const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime(); ph_acc[k] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
+#define SAT_PHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(a.phase + k, ph_acc[k]); } while (0)
+#else
+#define SAT_PHASE_INIT
+#define SAT_PHASE(k)
+#define SAT_PHASE_FLUSH
+#endif
 
 // N1P: pitch of the query cell matrix (>= 4*ceil(n1/4)); M2W: 32-bit words of a db-side
 // bit set (n2 <= 32*M2W); QLDS: query cells staged in LDS (else read through L1/L2).
 template <int N1P, int M2W, bool QLDS>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
 sat_sa_kernel(const SatKernelArgs a)
 {
     using namespace satk;
@@ -310,6 +385,7 @@ sat_sa_kernel(const SatKernelArgs a)
     const int e = a.entry_list[blockIdx.x];
     const SatQuery Q = a.queries[blockIdx.y];
     const int n1 = Q.n1;
+    const double n1d = (double)n1;
     const int n2 = a.orders[e];
     const int n2p = n2 + 1;
     const int n1w = (n1 + 3) >> 2;
@@ -411,8 +487,13 @@ sat_sa_kernel(const SatKernelArgs a)
     uint32_t best_restart = 0xFFFFFFFFu;
     bool any = false;
 
+    SAT_PHASE_INIT;
+#ifdef SAT_EXP_PERTURB
+    uint32_t pert[4] = { (uint32_t)lane_id, 1u, 2u, 3u };
+#endif
     for (int restart = tid; restart < a.maxstart; restart += T) {
         any = true;
+        SAT_PHASE(7);
         const uint64_t subseq = subseq_lo | ((uint64_t)(uint32_t)restart << 32);
 
         // ---- random initial map (thinit, K.cu:588-648): order preserving, types respected
@@ -477,31 +558,67 @@ sat_sa_kernel(const SatKernelArgs a)
         }
 
         // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
+        SAT_PHASE(6);                     // thinit + full score
         for (int iter = 0; iter < SAT_K_MAXITER; iter++) {
             const uint4 r = philox_block(Q.seed_q, subseq, (uint32_t)(SAT_K_STEP_BLOCK0 + iter));
+#ifdef SAT_EXP_PERTURB
+            satk::perturb(pert);
+#endif
 
             // which query SSE moves (K.cu:1037-1042)
-            const int ssei = scaled_index(to_uniform(r.x), n1);
-            const int oldj = smap_b[map_byte_addr(ssei)];
+            const int ssei = scaled_index(draw32(r.x), n1d);
 
             // candidate db SSEs: free, same type, inside the order window (K.cu:1053-1086)
-            int startj = 0, endj = n2;
-            if (a.lorder) {
-                Bits<M1W> upto = bits_below<M1W>(ssei + 1), lowpart, highpart;
-#pragma unroll
-                for (int w = 0; w < M1W; w++) {
-                    lowpart.w[w] = mapped.w[w] & upto.w[w];
-                    highpart.w[w] = mapped.w[w] & ~upto.w[w];
-                }
-                const int p = bits_highest<M1W>(lowpart);
-                const int q = bits_lowest<M1W>(highpart);
-                const int pimg = smap_b[map_byte_addr(p < 0 ? 0 : p)];
-                const int qimg = smap_b[map_byte_addr(q < 0 ? 0 : q)];
-                startj = p < 0 ? n2 : pimg;                      // no mapped predecessor: empty window
-                endj = (ssei == n1 - 1) ? n2 : (q < 0 ? -1 : qimg);   // K.cu:1064-1077
-            }
+            int oldj;
             Bits<M2W> cand;
-            {
+            if (M2W == 1 && a.lorder) {
+                // LORDER maps are order preserving (thinit builds them so and every move stays
+                // inside its window), so the images of the mapped query SSEs are the set bits of
+                // `occ` in the same order.  With p = highest mapped query SSE <= ssei and A its
+                // image, the window [startj, endj) of K.cu:1053-1077 is the run of free bits
+                // between A and the next occupied bit above it: no second and third map read, no
+                // range masks.  p == ssei exactly when ssei is mapped, so A is also its old image.
+                Bits<M1W> lowpart;
+                int p;
+                bool none;
+                if constexpr (M1W == 1) {
+                    lowpart.w[0] = mapped.w[0] & (0xFFFFFFFFu >> (31 - ssei));
+                    p = 31 ^ __builtin_clz(lowpart.w[0] | 1u);
+                    none = lowpart.w[0] == 0u;
+                } else {
+                    Bits<M1W> upto = bits_below<M1W>(ssei + 1);
+#pragma unroll
+                    for (int w = 0; w < M1W; w++) lowpart.w[w] = mapped.w[w] & upto.w[w];
+                    p = bits_highest<M1W>(lowpart);
+                    none = p < 0;
+                    p = none ? 0 : p;
+                }
+                const int A = smap_b[map_byte_addr(p)];
+                oldj = p == ssei ? A : NULLJ;
+                const uint32_t above = 0xFFFFFFFEu << (A & 31);          // bits A+1 .. 31
+                const uint32_t y = occ.w[0] & above;                     // occupied above A
+                const uint32_t gap = (y - 1u) & ~y & above;              // free run up to the next occupied bit
+                // no mapped SSE at or below ssei: startj = n2, empty (K.cu:1060-1063); no mapped
+                // successor: endj = -1, empty, unless ssei is the last query SSE (K.cu:1064-1077)
+                const bool empty = none || (y == 0u && ssei != n1 - 1);
+                cand.w[0] = empty ? 0u : (tmask[qtypes[ssei] * 4] & gap);
+            } else {
+                oldj = smap_b[map_byte_addr(ssei)];
+                int startj = 0, endj = n2;
+                if (a.lorder) {
+                    Bits<M1W> upto = bits_below<M1W>(ssei + 1), lowpart, highpart;
+#pragma unroll
+                    for (int w = 0; w < M1W; w++) {
+                        lowpart.w[w] = mapped.w[w] & upto.w[w];
+                        highpart.w[w] = mapped.w[w] & ~upto.w[w];
+                    }
+                    const int p = bits_highest<M1W>(lowpart);
+                    const int q = bits_lowest<M1W>(highpart);
+                    const int pimg = smap_b[map_byte_addr(p < 0 ? 0 : p)];
+                    const int qimg = smap_b[map_byte_addr(q < 0 ? 0 : q)];
+                    startj = p < 0 ? n2 : pimg;                      // no mapped predecessor: empty window
+                    endj = (ssei == n1 - 1) ? n2 : (q < 0 ? -1 : qimg);   // K.cu:1064-1077
+                }
                 const int t = qtypes[ssei];
                 Bits<M2W> lo = bits_below<M2W>(startj), hi = bits_below<M2W>(endj);
 #pragma unroll
@@ -512,7 +629,7 @@ sat_sa_kernel(const SatKernelArgs a)
             // (K.cu:701-702); several: the draw picks the (u - EPS) * cnt -th (K.cu:705-711).
             // Branch-free: in a 64-lane wave every case occurs anyway.
             const int cnt = bits_count<M2W>(cand);
-            const int pick = cnt > 1 ? scaled_index(to_uniform(r.y), cnt) : 0;
+            const int pick = cnt > 1 ? scaled_index(draw32(r.y), (double)cnt) : 0;
             int sel;
             if (M2W == 1 && a.lorder) {
                 // inside an order window the picked rank is small (few free same-type SSEs): strip
@@ -530,6 +647,7 @@ sat_sa_kernel(const SatKernelArgs a)
             }
             const int newj = cnt == 0 ? NULLJ : sel;
 
+            SAT_PHASE(0);                 // draw + proposal
             // score change (deltasd, K.cu:502-535)
             int delta;
             {
@@ -568,31 +686,39 @@ sat_sa_kernel(const SatKernelArgs a)
                     // active-lane rank -> (item of the round, map word)
                     const int sub = __mul24(lane64, recip) >> 16, kw = lane64 - __mul24(sub, n1w);
                     const bool quads = (n1w & 3) == 0;
-                    for (int base = 0; base < total_items; base += per_round) {
+                    SAT_PHASE(1);         // compaction set-up
+                    const bool lane_ok = sub < per_round;
+                    auto add_up = [&](int v, bool ok, lds_i32_t *slot) {
+                        if (quads) {
+                            // items are aligned groups of n1w = 4m lanes: add up each quad of lanes with
+                            // two DPP moves, so that a quarter of the lanes hit the owner's accumulator
+                            v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                            v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+                            if (ok && (kw & 3) == 0)
+                                __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        } else if (ok) {
+                            __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    };
+                    int base = 0;
+                    for (; base < total_items; base += per_round) {
                         const int idx = base + sub;
-                        if (sub < per_round && idx < total_items && kw < n1w) {
+                        const bool ok = lane_ok && idx < total_items;
+                        int v = 0;
+                        if (ok) {
                             const uint32_t it = items[idx];
                             const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
-                            lds_i32_t *slot = (lds_i32_t *)(items + idx);
                             const uint32_t word = smap[kw * TP + owner];
                             const uint32_t qi = (uint32_t)(kw * N1P + si);
-                            int v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
+                            v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
                             v = (it >> 24) ? -v : v;
-                            if (quads) {
-                                // items are aligned groups of n1w = 4m lanes: add up each quad of lanes with
-                                // two DPP moves, so that a quarter of the lanes hit the owner's accumulator
-                                v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                                v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-                                if ((kw & 3) == 0)
-                                    __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            } else {
-                                __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            }
                         }
+                        add_up(v, ok, (lds_i32_t *)(items + (ok ? idx : 0)));
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    SAT_PHASE(2);         // compacted rounds
                     delta = 0;
                     if (nitems >= 1) delta = (int)(items[pre] - item1);
                     if (nitems == 2) delta += (int)(items[pre + 1] - item2);
@@ -619,6 +745,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 }
             }
             const int newscore = score + delta;
+            SAT_PHASE(3);                 // read-back (compacted) or the static loops
 
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
             if (newscore > best) {
@@ -630,13 +757,15 @@ sat_sa_kernel(const SatKernelArgs a)
                 }
             }
 
+            SAT_PHASE(4);                 // best tracking
             // Metropolis: accept iff expf(delta / temp) > u, via the host-built table
-            const float u = to_uniform(r.z);
+            // the table holds 2^32 * expf(.), compared with 2^32 * u: same decision, one multiply less
+            const float u = draw32(r.z);
             const int rowoff = a.prow[2 * iter], rowmax = a.prow[2 * iter + 1];
             // entry rowmax + 1 of every row is 0.0: larger -delta can never be accepted
             const int nd = min(max(-delta, 0), rowmax + 1);
             const float ptable = a.ptab[rowoff + nd];
-            const float p = delta > 0 ? 2.0f : ptable;            // expf(x > 0) > 1 >= u
+            const float p = delta > 0 ? 8589934592.0f : ptable;   // expf(x > 0) > 1 >= u
             const bool accept = p > u;
             if (accept) smap_b[map_byte_addr(ssei)] = (uint8_t)newj;
             score = accept ? newscore : score;
@@ -664,8 +793,13 @@ sat_sa_kernel(const SatKernelArgs a)
 #pragma unroll
                 for (int w = 0; w < M1W; w++) mapped.w[w] = accept ? mapped2.w[w] : mapped.w[w];
             }
+            SAT_PHASE(5);                 // Metropolis + state update
         }
     }
+    SAT_PHASE_FLUSH;
+#ifdef SAT_EXP_PERTURB
+    if ((pert[0] ^ pert[1] ^ pert[2] ^ pert[3]) == 0xDEADBEEFu) Q.scores[e] = -1;
+#endif
 
     // ---- arg-max over restarts; ties go to the lowest restart index, which is the
     // first restart that reaches the maximum in the reference's sequential order

@@ -14,8 +14,10 @@
  * code otherwise; sat_last_error() has the text.  Nothing in the library calls
  * exit() or abort().  Environment (tuning / test overrides of launch heuristics, results do
  * not depend on them): SAT_EXP_LPC = 0|1|2 (log2 lanes per chain), SAT_EXP_COMPACT = 0|1
- * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS).  There is no CPU fallback: without a usable HIP device
- * sat_ctx_create() fails with SAT_ENODEVICE.
+ * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS),
+ * SAT_EXP_LDS_PAD = bytes (unused LDS added per workgroup: occupancy experiments).
+ * There is no CPU fallback: without a usable HIP device sat_ctx_create() fails with
+ * SAT_ENODEVICE.
  */
 #ifndef SATABSEARCH_H
 #define SATABSEARCH_H
