@@ -120,27 +120,39 @@ void free_db(sat_ctx *ctx)
 
 typedef void (*kernel_fn)(const SatKernelArgs);
 
-template <int N1P> kernel_fn pick_m2w(int m2w, bool qlds)
+template <int N1P, bool QLDS, bool FAST, int WPL> kernel_fn pick_m2w(int m2w)
 {
-    if (qlds) {
-        if (m2w == 1) return sat_sa_kernel<N1P, 1, true>;
-        if (m2w == 2) return sat_sa_kernel<N1P, 2, true>;
-        return sat_sa_kernel<N1P, 4, true>;
-    }
-    {
-        if (m2w == 1) return sat_sa_kernel<N1P, 1, false>;
-        if (m2w == 2) return sat_sa_kernel<N1P, 2, false>;
-        return sat_sa_kernel<N1P, 4, false>;
-    }
+    if (m2w == 1) return sat_sa_kernel<N1P, 1, QLDS, FAST, WPL>;
+    if (m2w == 2) return sat_sa_kernel<N1P, 2, QLDS, FAST, WPL>;
+    return sat_sa_kernel<N1P, 4, QLDS, FAST, WPL>;
 }
 
-kernel_fn pick_kernel(int n1p, int m2w, bool qlds)
+// fast = LORDER, no LSOLN, one lane per chain, compaction tables present, and every query of the
+// launch with the same words-per-lane `wpl` (see the kernel's FAST and WPL parameters).  The fast
+// instantiations exist for the default placement of the query cells only (LDS for the 16 class,
+// L1/L2 for the others) and for the wpl values the class can have (satk::compaction_shape).
+template <int N1P> kernel_fn pick_n1p(int m2w, bool qlds, bool fast, int wpl)
+{
+    constexpr bool kQ = N1P < 32;
+    if (fast && qlds == kQ) {
+        if (wpl == 4) return pick_m2w<N1P, kQ, true, 4>(m2w);
+        if constexpr (N1P <= 64)
+            if (wpl == 3) return pick_m2w<N1P, kQ, true, 3>(m2w);
+        if constexpr (N1P == 16) {
+            if (wpl == 2) return pick_m2w<N1P, kQ, true, 2>(m2w);
+            if (wpl == 1) return pick_m2w<N1P, kQ, true, 1>(m2w);
+        }
+    }
+    return qlds ? pick_m2w<N1P, true, false, 0>(m2w) : pick_m2w<N1P, false, false, 0>(m2w);
+}
+
+kernel_fn pick_kernel(int n1p, int m2w, bool qlds, bool fast, int wpl)
 {
     switch (n1p) {
-    case 16: return pick_m2w<16>(m2w, qlds);
-    case 32: return pick_m2w<32>(m2w, qlds);
-    case 64: return pick_m2w<64>(m2w, qlds);
-    default: return pick_m2w<112>(m2w, qlds);
+    case 16: return pick_n1p<16>(m2w, qlds, fast, wpl);
+    case 32: return pick_n1p<32>(m2w, qlds, fast, wpl);
+    case 64: return pick_n1p<64>(m2w, qlds, fast, wpl);
+    default: return pick_n1p<112>(m2w, qlds, fast, wpl);
     }
 }
 
@@ -179,6 +191,7 @@ int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
     for (int c = 0; c < 4; c++) {
         ctx->class_begin[c] = (int)desc.size();
         ctx->class_n1max[c] = 0;
+        ctx->class_wpl[c] = -1;                       // -1: no query yet, 0: mixed
         for (size_t qi = 0; qi < nq; qi++) {
             const auto &q = ctx->queries[qi];
             if (q.n1p != kClassN1P[c]) continue;
@@ -194,7 +207,11 @@ int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
             d.ssemaps = lsoln ? ctx->d_ssemaps + q.ssemap_off : nullptr;
             desc.push_back(d);
             if (q.n1 > ctx->class_n1max[c]) ctx->class_n1max[c] = q.n1;
+            int lpi, wpl;
+            satk::compaction_shape((q.n1 + 3) >> 2, lpi, wpl);
+            ctx->class_wpl[c] = ctx->class_wpl[c] < 0 ? wpl : (ctx->class_wpl[c] == wpl ? wpl : 0);
         }
+        if (ctx->class_wpl[c] < 0) ctx->class_wpl[c] = 0;
     }
     ctx->class_begin[4] = (int)desc.size();
     // ordered after earlier launches on the stream; the host vector dies at return, so wait
@@ -308,7 +325,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             }
             a.lpc_shift = lpc_shift;
             a.compact = compact ? 1 : 0;
-            kernel_fn fn = pick_kernel(n1p, m2w, qlds);
+            const bool fast = lorder != 0 && lsoln == 0 && lpc_shift == 0 && compact && !getenv("SAT_EXP_GENERAL");
+            kernel_fn fn = pick_kernel(n1p, m2w, qlds, fast, ctx->class_wpl[c]);
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));

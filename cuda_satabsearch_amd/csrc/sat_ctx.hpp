@@ -37,6 +37,7 @@ struct sat_ctx {
     SatQuery *d_qdesc = nullptr;            // descriptors grouped by size class
     int class_begin[5] = { 0, 0, 0, 0, 0 };  // classes: n1p = 16, 32, 64, 112
     int class_n1max[4] = { 0, 0, 0, 0 };
+    int class_wpl[4] = { 0, 0, 0, 0 };       // map words per lane shared by the class's queries, 0 = mixed
     bool desc_dirty = true;
     bool desc_lsoln = false;
 

@@ -76,7 +76,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#include <rocrand/rocrand_kernel.h>
+#include <type_traits>
 #include <stdint.h>
 
 #define SAT_K_MAXITER 100
@@ -302,6 +302,21 @@ __device__ __forceinline__ int scaled_index(float w, double n)
     return (int)(__builtin_fma((double)w, 2.3283064365386963e-10, -SAT_K_EPS) * n);
 }
 
+// Work compaction (SA step): a listed row is served by `lpi` lanes, each taking `wpl` <= 4 map
+// words (word kw, kw + lpi, ...), so the map of a chain is padded to wpl * lpi >= n1w words.
+__host__ __device__ inline void compaction_shape(int n1w, int &lpi, int &wpl)
+{
+    lpi = (n1w + 3) >> 2;
+    wpl = lpi > 0 ? (n1w + lpi - 1) / lpi : 1;
+    if (lpi < 1) lpi = 1;
+}
+__host__ __device__ inline int map_words(int n1w)
+{
+    int lpi, wpl;
+    compaction_shape(n1w, lpi, wpl);
+    return lpi * wpl;
+}
+
 // LDS byte size of one workgroup
 __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains, int threads, bool lsoln, bool q_in_lds,
                                              bool compact)
@@ -311,7 +326,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
     size_t bytes = dcells * 8;
     if (q_in_lds) bytes += n1w * (size_t)n1p * 20;            // float4 + code dword per (group, column)
-    bytes += n1w * (chains + 1) * 4;                          // map words, row stride chains + 1 (bank skew)
+    bytes += (size_t)map_words((int)n1w) * (chains + 1) * 4;  // map words (padded), row stride chains + 1 (bank skew)
     (void)lsoln;                                              // the best maps live in global memory
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
@@ -367,7 +382,12 @@ __device__ __forceinline__ void perturb(uint32_t (&d)[4])
 
 // N1P: pitch of the query cell matrix (>= 4*ceil(n1/4)); M2W: 32-bit words of a db-side
 // bit set (n2 <= 32*M2W); QLDS: query cells staged in LDS (else read through L1/L2).
-template <int N1P, int M2W, bool QLDS>
+// FAST: the options of a plain search are compile-time facts (LORDER = T, LSOLN = F, one lane
+// per chain, work compaction available); the host launches such an instantiation when they hold
+// and the general one otherwise.  Same code, but the option tests leave the SA step loop.
+// WPL: map words per lane in the compacted rounds (satk::compaction_shape) when every query of
+// the launch has the same; 0 = read it from the query (a four-way switch per step).
+template <int N1P, int M2W, bool QLDS, bool FAST, int WPL>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
 sat_sa_kernel(const SatKernelArgs a)
 {
@@ -378,10 +398,13 @@ sat_sa_kernel(const SatKernelArgs a)
     const int lane_id = threadIdx.x;
     const int nthreads = blockDim.x;
     // chain = restart slot of this lane; `part` of `lpc` adjacent lanes share one chain
-    const int lpc = 1 << a.lpc_shift;
-    const int tid = lane_id >> a.lpc_shift;       // chain index inside the workgroup
+    const int lpc_shift = FAST ? 0 : a.lpc_shift;
+    const bool opt_lorder = FAST ? true : a.lorder != 0;
+    const bool opt_compact = FAST ? true : a.compact != 0;
+    const int lpc = 1 << lpc_shift;
+    const int tid = lane_id >> lpc_shift;         // chain index inside the workgroup
     const int part = lane_id & (lpc - 1);
-    const int T = nthreads >> a.lpc_shift;        // chains per workgroup
+    const int T = nthreads >> lpc_shift;          // chains per workgroup
     const int e = a.entry_list[blockIdx.x];
     const SatQuery Q = a.queries[blockIdx.y];
     const int n1 = Q.n1;
@@ -390,7 +413,7 @@ sat_sa_kernel(const SatKernelArgs a)
     const int n2p = n2 + 1;
     const int n1w = (n1 + 3) >> 2;
     const int NULLJ = n2;                       // the null db SSE
-    const bool lsoln = a.lsoln != 0;
+    const bool lsoln = FAST ? false : a.lsoln != 0;
 
     // ---- carve LDS (must match satk::lds_bytes)
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
@@ -403,7 +426,11 @@ sat_sa_kernel(const SatKernelArgs a)
     // one chain in different banks (the compacted loop reads them from n1w lanes at once) and
     // keeps word w of all chains contiguous for the static loops
     const int TP = T + 1;
-    uint32_t *tmask = smap + (size_t)n1w * TP;
+    int cmp_lpi, cmp_wpl_q;
+    compaction_shape(n1w, cmp_lpi, cmp_wpl_q);
+    const int cmp_wpl = WPL > 0 ? WPL : cmp_wpl_q;           // the host launches WPL > 0 only where it matches
+    const int cmp_words = cmp_lpi * cmp_wpl;                 // words n1w .. cmp_words - 1 stay "unmatched"
+    uint32_t *tmask = smap + (size_t)cmp_words * TP;
     // best maps: word w of chain c at w*T + c of this workgroup's slab (global memory)
     uint32_t *bmap = lsoln ? a.bmap_slabs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.bmap_slab_words : nullptr;
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
@@ -487,6 +514,15 @@ sat_sa_kernel(const SatKernelArgs a)
     uint32_t best_restart = 0xFFFFFFFFu;
     bool any = false;
 
+    // ---- work compaction constants (see the SA step).  A listed row is served by cmp_lpi lanes,
+    // each taking cmp_wpl <= 4 map words: the loads of a lane's words are in flight together and a
+    // round holds 64 / cmp_lpi rows, so a typical step is one or two rounds.  lane / cmp_lpi by a
+    // 16-bit reciprocal (exact for lane <= 64); lane -> (item of the round, first map word).
+    const int cmp_recip = (65536 + cmp_lpi - 1) / cmp_lpi;
+    const int per_round = (64 * cmp_recip) >> 16;
+    const int sub = __mul24(lane_id & 63, cmp_recip) >> 16, kw = (lane_id & 63) - __mul24(sub, cmp_lpi);
+    const bool lane_ok = sub < per_round;
+    const uint32_t nullword = (uint32_t)NULLJ * 0x01010101u;     // a map word of unmatched SSEs
     SAT_PHASE_INIT;
 #ifdef SAT_EXP_PERTURB
     uint32_t pert[4] = { (uint32_t)lane_id, 1u, 2u, 3u };
@@ -500,8 +536,7 @@ sat_sa_kernel(const SatKernelArgs a)
         Bits<M1W> mapped = bits_zero<M1W>();
         Bits<M2W> occ = bits_zero<M2W>();
         {
-            const uint32_t nullword = (uint32_t)NULLJ * 0x01010101u;
-            for (int w = 0; w < n1w; w++) smap[w * TP + tid] = nullword;
+            for (int w = 0; w < cmp_words; w++) smap[w * TP + tid] = nullword;
             int j = 0;
             bool stopped = false;
             for (int i0 = 0; i0 < n1; i0 += 4) {
@@ -571,7 +606,7 @@ sat_sa_kernel(const SatKernelArgs a)
             // candidate db SSEs: free, same type, inside the order window (K.cu:1053-1086)
             int oldj;
             Bits<M2W> cand;
-            if (M2W == 1 && a.lorder) {
+            if (M2W == 1 && opt_lorder) {
                 // LORDER maps are order preserving (thinit builds them so and every move stays
                 // inside its window), so the images of the mapped query SSEs are the set bits of
                 // `occ` in the same order.  With p = highest mapped query SSE <= ssei and A its
@@ -605,7 +640,7 @@ sat_sa_kernel(const SatKernelArgs a)
             } else {
                 oldj = smap_b[map_byte_addr(ssei)];
                 int startj = 0, endj = n2;
-                if (a.lorder) {
+                if (opt_lorder) {
                     Bits<M1W> upto = bits_below<M1W>(ssei + 1), lowpart, highpart;
 #pragma unroll
                     for (int w = 0; w < M1W; w++) {
@@ -631,7 +666,7 @@ sat_sa_kernel(const SatKernelArgs a)
             const int cnt = bits_count<M2W>(cand);
             const int pick = cnt > 1 ? scaled_index(draw32(r.y), (double)cnt) : 0;
             int sel;
-            if (M2W == 1 && a.lorder) {
+            if (M2W == 1 && opt_lorder) {
                 // inside an order window the picked rank is small (few free same-type SSEs): strip
                 // the lowest set bit `pick` times, looping while any lane of the wave still has to
                 uint32_t c = cand.w[0];
@@ -656,20 +691,9 @@ sat_sa_kernel(const SatKernelArgs a)
                 const int nitems = part == 0 ? (int)oreal + (int)nreal : 0;
                 const unsigned long long m1 = __ballot(nitems >= 1), m2 = __ballot(nitems == 2);
                 const int total_items = __popcll(m1) + __popcll(m2);           // wave-uniform
-                // consumers are the lanes that are in this step at all (a wave's last lanes may
-                // have no restart left): work is dealt by rank among them
-                const unsigned long long active = __ballot(1);
-                const int nactive = __popcll(active);
-                // n1w lanes per item; lane / n1w by a 16-bit reciprocal (exact for lane <= 64, n1w <= 28)
-                const int recip = (65536 + n1w - 1) / n1w;
-                const int per_round = (64 * recip) >> 16;
-                // cost model in SIMD cycles, from the opcode table: a round of the compacted loop is
-                // ~155 and its set-up ~100; the static loops cost ~85 per (row, word) = 170 per word.
-                // Full waves only (rank arithmetic stays shifts).
-                const int rounds = (total_items * n1w + 63) >> 6;                 // >= ceil(items / per_round) - 1
-                if (a.compact && nactive == 64 && total_items <= 64 && rounds * 155 + 100 < 170 * n1w) {
-                    const int lane64 = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32),
-                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0));
+                // only full waves compact (a wave's last lanes may have no restart left), so a lane's
+                // rank among the consumers is its lane number; see cmp_* above the restart loop
+                if (opt_compact && __ballot(1) == ~0ull && total_items <= 64) {
                     const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0)) +
                                     __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
                     // item = row | moved SSE << 8 | owner chain << 16 | negate << 24.  The slot doubles as
@@ -683,37 +707,53 @@ sat_sa_kernel(const SatKernelArgs a)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // active-lane rank -> (item of the round, map word)
-                    const int sub = __mul24(lane64, recip) >> 16, kw = lane64 - __mul24(sub, n1w);
-                    const bool quads = (n1w & 3) == 0;
                     SAT_PHASE(1);         // compaction set-up
-                    const bool lane_ok = sub < per_round;
+                    // signed sum of a lane's words -> the row's accumulator (its item slot)
                     auto add_up = [&](int v, bool ok, lds_i32_t *slot) {
-                        if (quads) {
-                            // items are aligned groups of n1w = 4m lanes: add up each quad of lanes with
-                            // two DPP moves, so that a quarter of the lanes hit the owner's accumulator
+                        if ((cmp_lpi & 3) == 0) {
+                            // rows are aligned groups of 4m lanes: add up each quad of lanes with two
+                            // DPP moves, so that a quarter of the lanes hit the accumulator
                             v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
                             v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-                            if (ok && (kw & 3) == 0)
-                                __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        } else if (ok) {
-                            __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            ok = ok && (kw & 3) == 0;
+                        }
+                        if (ok) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    };
+                    auto rounds_of = [&](auto wtag) {
+                        constexpr int W = decltype(wtag)::value;      // == cmp_wpl
+                        for (int base = 0; base < total_items; base += per_round) {
+                            const int idx = base + sub;
+                            const bool ok = lane_ok && idx < total_items;
+                            int v = 0;
+                            if (ok) {
+                                const uint32_t it = items[idx];
+                                const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
+                                const uint2 *drow = Dc + __mul24(row, n2p);
+                                float4 qd[W];
+                                uint32_t qc[W], wd[W];
+#pragma unroll
+                                for (int u = 0; u < W; u++) {
+                                    // words past the map (a lane's last one, when cmp_lpi does not divide
+                                    // n1w) are padding: unmatched SSEs against the query's sentinel cells
+                                    const int kwu = kw + u * cmp_lpi;
+                                    wd[u] = smap[kwu * TP + owner];
+                                    const uint32_t qi = (uint32_t)(kwu * N1P + si);
+                                    qd[u] = load_qdist(qi);
+                                    qc[u] = load_qcode(qi);
+                                }
+#pragma unroll
+                                for (int u = 0; u < W; u++) v = quad_terms(qd[u], qc[u], drow, wd[u], 0u, v);
+                                v = (it >> 24) ? -v : v;
+                            }
+                            add_up(v, ok, (lds_i32_t *)(items + (ok ? idx : 0)));
                         }
                     };
-                    int base = 0;
-                    for (; base < total_items; base += per_round) {
-                        const int idx = base + sub;
-                        const bool ok = lane_ok && idx < total_items;
-                        int v = 0;
-                        if (ok) {
-                            const uint32_t it = items[idx];
-                            const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
-                            const uint32_t word = smap[kw * TP + owner];
-                            const uint32_t qi = (uint32_t)(kw * N1P + si);
-                            v = quad_terms(load_qdist(qi), load_qcode(qi), Dc + __mul24(row, n2p), word, 0u, 0);
-                            v = (it >> 24) ? -v : v;
-                        }
-                        add_up(v, ok, (lds_i32_t *)(items + (ok ? idx : 0)));
+                    if constexpr (WPL > 0) rounds_of(std::integral_constant<int, WPL>{});
+                    else switch (cmp_wpl) {
+                    case 1: rounds_of(std::integral_constant<int, 1>{}); break;
+                    case 2: rounds_of(std::integral_constant<int, 2>{}); break;
+                    case 3: rounds_of(std::integral_constant<int, 3>{}); break;
+                    default: rounds_of(std::integral_constant<int, 4>{}); break;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
