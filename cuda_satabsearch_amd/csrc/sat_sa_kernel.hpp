@@ -522,6 +522,13 @@ sat_sa_kernel(const SatKernelArgs a)
     const int per_round = (64 * cmp_recip) >> 16;
     const int sub = __mul24(lane_id & 63, cmp_recip) >> 16, kw = (lane_id & 63) - __mul24(sub, cmp_lpi);
     const bool lane_ok = sub < per_round;
+    // tail shapes: one word per lane (n1w lanes per row) and two words per lane, used for the last
+    // rows of a step when they fit one round of that shape; the two-word shape only if its padded
+    // word count stays inside the map's
+    const int tail1_recip = (65536 + n1w - 1) / n1w, tail1_rows = (64 * tail1_recip) >> 16;
+    const int tail2_lpi = (n1w + 1) >> 1;
+    const int tail2_recip = (65536 + tail2_lpi - 1) / tail2_lpi;
+    const int tail2_rows = 2 * tail2_lpi <= cmp_words ? (64 * tail2_recip) >> 16 : 0;
     const uint32_t nullword = (uint32_t)NULLJ * 0x01010101u;     // a map word of unmatched SSEs
     SAT_PHASE_INIT;
 #ifdef SAT_EXP_PERTURB
@@ -708,52 +715,69 @@ sat_sa_kernel(const SatKernelArgs a)
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     SAT_PHASE(1);         // compaction set-up
-                    // signed sum of a lane's words -> the row's accumulator (its item slot)
-                    auto add_up = [&](int v, bool ok, lds_i32_t *slot) {
-                        if ((cmp_lpi & 3) == 0) {
+                    // one round: the rows first .. first + 64 / lpi - 1 of the table, `lpi` lanes per row
+                    // (lane `rsub` of the round serves row first + rsub, words rkw, rkw + lpi, ...)
+                    auto one_round = [&](auto wtag, int first, int lpi, int rsub, int rkw, bool rlane_ok) {
+                        constexpr int W = decltype(wtag)::value;
+                        const int idx = first + rsub;
+                        bool ok = rlane_ok && idx < total_items;
+                        int v = 0;
+                        if (ok) {
+                            const uint32_t it = items[idx];
+                            const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
+                            const uint2 *drow = Dc + __mul24(row, n2p);
+                            float4 qd[W];
+                            uint32_t qc[W], wd[W];
+#pragma unroll
+                            for (int u = 0; u < W; u++) {
+                                // words past the map (a lane's last one, when lpi does not divide n1w)
+                                // are padding: unmatched SSEs against the query's sentinel cells
+                                const int kwu = rkw + u * lpi;
+                                wd[u] = smap[kwu * TP + owner];
+                                const uint32_t qi = (uint32_t)(kwu * N1P + si);
+                                qd[u] = load_qdist(qi);
+                                qc[u] = load_qcode(qi);
+                            }
+#pragma unroll
+                            for (int u = 0; u < W; u++) v = quad_terms(qd[u], qc[u], drow, wd[u], 0u, v);
+                            v = (it >> 24) ? -v : v;
+                        }
+                        // signed sum of a lane's words -> the row's accumulator (its item slot)
+                        if ((lpi & 3) == 0) {
                             // rows are aligned groups of 4m lanes: add up each quad of lanes with two
                             // DPP moves, so that a quarter of the lanes hit the accumulator
                             v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
                             v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-                            ok = ok && (kw & 3) == 0;
+                            ok = ok && (rkw & 3) == 0;
                         }
-                        if (ok) __hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (ok)
+                            __hip_atomic_fetch_add((lds_i32_t *)(items + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     };
-                    auto rounds_of = [&](auto wtag) {
-                        constexpr int W = decltype(wtag)::value;      // == cmp_wpl
-                        for (int base = 0; base < total_items; base += per_round) {
-                            const int idx = base + sub;
-                            const bool ok = lane_ok && idx < total_items;
-                            int v = 0;
-                            if (ok) {
-                                const uint32_t it = items[idx];
-                                const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
-                                const uint2 *drow = Dc + __mul24(row, n2p);
-                                float4 qd[W];
-                                uint32_t qc[W], wd[W];
-#pragma unroll
-                                for (int u = 0; u < W; u++) {
-                                    // words past the map (a lane's last one, when cmp_lpi does not divide
-                                    // n1w) are padding: unmatched SSEs against the query's sentinel cells
-                                    const int kwu = kw + u * cmp_lpi;
-                                    wd[u] = smap[kwu * TP + owner];
-                                    const uint32_t qi = (uint32_t)(kwu * N1P + si);
-                                    qd[u] = load_qdist(qi);
-                                    qc[u] = load_qcode(qi);
-                                }
-#pragma unroll
-                                for (int u = 0; u < W; u++) v = quad_terms(qd[u], qc[u], drow, wd[u], 0u, v);
-                                v = (it >> 24) ? -v : v;
-                            }
-                            add_up(v, ok, (lds_i32_t *)(items + (ok ? idx : 0)));
+                    auto main_round = [&](int first) {
+                        if constexpr (WPL > 0) one_round(std::integral_constant<int, WPL>{}, first, cmp_lpi, sub, kw, lane_ok);
+                        else switch (cmp_wpl) {
+                        case 1: one_round(std::integral_constant<int, 1>{}, first, cmp_lpi, sub, kw, lane_ok); break;
+                        case 2: one_round(std::integral_constant<int, 2>{}, first, cmp_lpi, sub, kw, lane_ok); break;
+                        case 3: one_round(std::integral_constant<int, 3>{}, first, cmp_lpi, sub, kw, lane_ok); break;
+                        default: one_round(std::integral_constant<int, 4>{}, first, cmp_lpi, sub, kw, lane_ok); break;
                         }
                     };
-                    if constexpr (WPL > 0) rounds_of(std::integral_constant<int, WPL>{});
-                    else switch (cmp_wpl) {
-                    case 1: rounds_of(std::integral_constant<int, 1>{}); break;
-                    case 2: rounds_of(std::integral_constant<int, 2>{}); break;
-                    case 3: rounds_of(std::integral_constant<int, 3>{}); break;
-                    default: rounds_of(std::integral_constant<int, 4>{}); break;
+                    // full rounds of the main shape while more rows remain than one round holds; the
+                    // last rows go to the shape with the fewest words per lane that still takes them in
+                    // one round (a step lists ~0.6 rows per chain: the tail is usually a few rows)
+                    int first = 0;
+                    for (; total_items - first > per_round; first += per_round) main_round(first);
+                    const int rest = total_items - first;
+                    if (rest > 0) {
+                        if (cmp_wpl > 1 && rest <= tail1_rows) {
+                            const int l = lane_id & 63, rsub = __mul24(l, tail1_recip) >> 16;
+                            one_round(std::integral_constant<int, 1>{}, first, n1w, rsub, l - __mul24(rsub, n1w), rsub < tail1_rows);
+                        } else if (cmp_wpl > 2 && rest <= tail2_rows) {
+                            const int l = lane_id & 63, rsub = __mul24(l, tail2_recip) >> 16;
+                            one_round(std::integral_constant<int, 2>{}, first, tail2_lpi, rsub, l - __mul24(rsub, tail2_lpi), rsub < tail2_rows);
+                        } else {
+                            main_round(first);
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
