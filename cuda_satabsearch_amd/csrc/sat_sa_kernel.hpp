@@ -450,6 +450,8 @@ sat_sa_kernel(const SatKernelArgs a)
     const gptr_f4 qdistG = (gptr_f4)(uintptr_t)Q.qdist;
     const gptr_u32 qcodeG = (gptr_u32)(uintptr_t)Q.qcode;
     typedef const __attribute__((address_space(1))) char *gptr_c;
+    typedef const __attribute__((address_space(4))) int32_t *cptr_i32;
+    const cptr_i32 prowC = (cptr_i32)(uintptr_t)a.prow;
     // uniform 64-bit base + 32-bit byte offset: the saddr form of global_load, no 64-bit VALU math
     auto load_qdist = [&](uint32_t idx) -> float4 {
         if constexpr (QLDS) return qdistL[idx];
@@ -678,7 +680,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 // the lowest set bit `pick` times, looping while any lane of the wave still has to
                 uint32_t c = cand.w[0];
                 int left = pick;
-                while (__any(left > 0)) {
+                while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
                     const bool go = left > 0;
                     c = go ? (c & (c - 1u)) : c;
                     left -= go ? 1 : 0;
@@ -695,12 +697,14 @@ sat_sa_kernel(const SatKernelArgs a)
             {
                 // rows of this step that are real, listed once per chain (part 0 of its lanes)
                 const bool oreal = oldj != NULLJ, nreal = newj != NULLJ;
-                const int nitems = part == 0 ? (int)oreal + (int)nreal : 0;
-                const unsigned long long m1 = __ballot(nitems >= 1), m2 = __ballot(nitems == 2);
+                const bool lists = part == 0;
+                const int nitems = lists ? (int)oreal + (int)nreal : 0;
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lists && (oreal || nreal)),
+                                         m2 = __builtin_amdgcn_ballot_w64(lists && oreal && nreal);
                 const int total_items = __popcll(m1) + __popcll(m2);           // wave-uniform
                 // only full waves compact (a wave's last lanes may have no restart left), so a lane's
                 // rank among the consumers is its lane number; see cmp_* above the restart loop
-                if (opt_compact && __ballot(1) == ~0ull && total_items <= 64) {
+                if (opt_compact && __builtin_amdgcn_ballot_w64(true) == ~0ull && total_items <= 64) {
                     const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0)) +
                                     __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0));
                     // item = row | moved SSE << 8 | owner chain << 16 | negate << 24.  The slot doubles as
@@ -825,7 +829,10 @@ sat_sa_kernel(const SatKernelArgs a)
             // Metropolis: accept iff expf(delta / temp) > u, via the host-built table
             // the table holds 2^32 * expf(.), compared with 2^32 * u: same decision, one multiply less
             const float u = draw32(r.z);
-            const int rowoff = a.prow[2 * iter], rowmax = a.prow[2 * iter + 1];
+            // the row directory is read-only for the kernel's lifetime: through the constant address
+            // space these are scalar loads (a plain global pointer gets a vector load here, whose
+            // latency would sit in front of the table load below)
+            const int rowoff = prowC[2 * iter], rowmax = prowC[2 * iter + 1];
             // entry rowmax + 1 of every row is 0.0: larger -delta can never be accepted
             const int nd = min(max(-delta, 0), rowmax + 1);
             const float ptable = a.ptab[rowoff + nd];
