@@ -604,6 +604,11 @@ sat_sa_kernel(const SatKernelArgs a)
         // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
         SAT_PHASE(6);                     // thinit + full score
         for (int iter = 0; iter < SAT_K_MAXITER; iter++) {
+            // this step's row of the Metropolis table.  The directory is read-only for the kernel's
+            // lifetime: through the constant address space these are scalar loads (a plain global
+            // pointer gets a vector load, whose latency would sit in front of the table load), asked
+            // for here so that they are back long before the test at the end of the step
+            const int rowoff = prowC[2 * iter], rowmax = prowC[2 * iter + 1];
             const uint4 r = philox_block(Q.seed_q, subseq, (uint32_t)(SAT_K_STEP_BLOCK0 + iter));
 #ifdef SAT_EXP_PERTURB
             satk::perturb(pert);
@@ -829,10 +834,6 @@ sat_sa_kernel(const SatKernelArgs a)
             // Metropolis: accept iff expf(delta / temp) > u, via the host-built table
             // the table holds 2^32 * expf(.), compared with 2^32 * u: same decision, one multiply less
             const float u = draw32(r.z);
-            // the row directory is read-only for the kernel's lifetime: through the constant address
-            // space these are scalar loads (a plain global pointer gets a vector load here, whose
-            // latency would sit in front of the table load below)
-            const int rowoff = prowC[2 * iter], rowmax = prowC[2 * iter + 1];
             // entry rowmax + 1 of every row is 0.0: larger -delta can never be accepted
             const int nd = min(max(-delta, 0), rowmax + 1);
             const float ptable = a.ptab[rowoff + nd];
