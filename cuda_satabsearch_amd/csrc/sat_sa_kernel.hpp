@@ -24,7 +24,7 @@
 //        smap[w*(T+1) + chain]: word w of every chain is contiguous, so a loop over a
 //        uniform word reads it conflict free; the odd row stride T+1 spreads the words of
 //        ONE chain over different banks for the compacted loop, where the lanes serving
-//        an item read that chain's n1w words in one instruction.
+//        a row read that chain's words in the same instruction.
 //   bmap (LSOLN only) best map so far of every chain, same word-interleaved layout but in
 //        GLOBAL memory (one slab per workgroup of the launch): it is written on improvements
 //        only and read once by the winner, the resident slabs (~4 KB x a few thousand
@@ -35,10 +35,15 @@
 // one in 27 % of the steps, both in 10 %, neither in 58 %): instead of every lane scoring
 // 2 rows x n1/4 map words for its own chain, the lanes of a wave list the rows that are real
 // (ballot + mbcnt prefix -> a per-wave item table in LDS: row, moved SSE, owner chain,
-// sign), then the WHOLE wave works through (item, map word) pairs, 64 at a time, each lane
-// adding its four-pair sum to the owner's accumulator with an LDS atomic.  A wave-step then
-// costs ~S*n1w/64 packed evaluations (S = real rows in the wave, ~33 of 128) instead of
-// 2*n1w per lane.  When most rows are real (S large) the static per-lane loops run instead.
+// sign), then the WHOLE wave works through them in rounds: a row is served by lpi =
+// ceil(n1w / 4) lanes, each taking up to four map words (word kw, kw + lpi, ...) whose loads
+// are issued together, a round holds 64 / lpi rows, and each lane adds its signed sum to the
+// row's accumulator (the item slot itself) with an LDS atomic.  The last few rows of a step
+// go to a tail shape with one or two words per lane (more lanes per row) rather than a mostly
+// empty full round.  Maps are padded to lpi * wpl words (padding = unmatched SSEs, which meet
+// the query's sentinel cells), so the rounds carry no validity tests.  A wave-step then costs
+// ~S*n1w/64 packed evaluations (S = real rows in the wave, ~37 of 128) instead of 2*n1w per
+// lane.  With LORDER = F most rows are real and the static per-lane loops run instead.
 //
 // Lanes per chain (lpc = 1, 2 or 4): when the cells of a large db entry leave room for
 // only a few workgroups per CU, lpc adjacent lanes run ONE chain together - every lane
@@ -64,9 +69,10 @@
 // 111-int candidate list (K.cu:677-714): occ = occupied db SSEs, mapped = matched
 // query SSEs, tmask[t] = db SSEs of type t.
 //
-// Random numbers: rocRAND Philox4x32-10 device API, one 4x32-bit block per SA step,
-// addressed by (seed, query, db ordinal, restart, step) - see oracle/sa_oracle.h for
-// the slot layout, which the CPU oracle restates bit for bit.
+// Random numbers: Philox4x32-10 with rocRAND's counter layout (rocrand_init(seed, subsequence,
+// offset) + rocrand4), written out in philox_block; one 4x32-bit block per SA step, addressed
+// by (seed, query, db ordinal, restart, step) - see oracle/sa_oracle.h for the slot layout,
+// which the CPU oracle restates bit for bit.
 //
 // Metropolis test: the reference evaluates expf((float)delta / temp) > u with glibc
 // expf on the host path (K.cu:1166).  temp takes 100 values and delta is a small
