@@ -10,7 +10,7 @@ with sat.Searcher(0) as s:
     s.upload(db); s.set_query(*q, 0)
     for lorder, lsoln, r in [(True, False, 128), (True, True, 128), (False, False, 128), (False, True, 128), (True, False, 4096)]:
         if r > 1000:
-            s.upload(sat.synth.make_db(2000, 32))
+            s.upload(sat.synth.make_db(6144, 32))      # 4 full rounds of 1536 resident workgroups
         s.search_timed(lorder, lsoln, r, 1)
         tot, _ = s.search_timed(lorder, lsoln, r, 2)
         ms = tot / 2

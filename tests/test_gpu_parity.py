@@ -134,6 +134,45 @@ def test_forced_execution_modes(searcher, monkeypatch, env):
         check(searcher, db, q, False, True, 100)
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["specialised", "general"])
+def test_round_shapes_of_every_query_order_class(searcher, wide_db, monkeypatch, general):
+    """The compacted rounds serve a listed row with ceil(n1w/4) lanes x up to 4 map words, pad the
+    maps to whole words per lane and send a step's last rows to 1- and 2-word shapes.  One query
+    order from every (lanes per row, words per lane, padding) class, LSOLN off so that the
+    option-specialised instantiations run, and again through the general kernel
+    (SAT_EXP_GENERAL), which picks the shape at run time."""
+    if general:
+        monkeypatch.setenv("SAT_EXP_GENERAL", "1")
+    searcher.upload(wide_db)
+    entries = np.arange(0, len(wide_db), 4)
+    for n1 in (3, 4, 8, 9, 12, 13, 19, 21, 24, 25, 28, 36, 37, 40, 45, 48, 52, 61, 68, 77, 84, 100, 109):
+        rng = np.random.default_rng(1000 + n1)
+        src = int(rng.choice(np.nonzero(wide_db.orders >= n1)[0]))
+        t, d = wide_db.dense(src)
+        sel = np.sort(rng.choice(int(wide_db.orders[src]), size=n1, replace=False))
+        q = (t[np.ix_(sel, sel)].copy(), d[np.ix_(sel, sel)].copy(), np.diagonal(t)[sel].copy())
+        check(searcher, wide_db, q, True, False, 64, entries=entries)
+
+
+def test_batch_of_mixed_round_shapes(searcher, wide_db):
+    """Queries of one size class but different words-per-lane counts in one batch: the launch
+    cannot use an instantiation with a fixed count and must still give every query's bits."""
+    searcher.upload(wide_db)
+    queries = []
+    for n1 in (17, 21, 24, 29, 32):          # 32 class: 3, 3, 3, 4, 4 words per lane
+        rng = np.random.default_rng(2000 + n1)
+        src = int(rng.choice(np.nonzero(wide_db.orders >= n1)[0]))
+        t, d = wide_db.dense(src)
+        sel = np.sort(rng.choice(int(wide_db.orders[src]), size=n1, replace=False))
+        queries.append((t[np.ix_(sel, sel)].copy(), d[np.ix_(sel, sel)].copy(), np.diagonal(t)[sel].copy()))
+    searcher.set_queries(queries, 5)
+    scores, _, _ = searcher.search(True, False, 64)
+    idx = np.arange(0, len(wide_db), 5)
+    for qi, (qt, qd, qtypes) in enumerate(queries):
+        oscores, _, _ = oracle_lib.search(wide_db, qt, qd, qtypes, True, False, 64, entries=idx, query_ordinal=5 + qi)
+        assert np.array_equal(scores[qi][idx], oscores), f"query {qi} of the batch differs"
+
+
 # ---------------------------------------------------------------- keys of the streams
 def test_sharding_does_not_change_results(searcher):
     db = sat.synth.make_db(600, 8, 32)
