@@ -120,39 +120,58 @@ void free_db(sat_ctx *ctx)
 
 typedef void (*kernel_fn)(const SatKernelArgs);
 
-template <int N1P, bool QLDS, bool FAST, int WPL> kernel_fn pick_m2w(int m2w)
+template <int N1P, bool QLDS, int OPT, int WPL> kernel_fn pick_m2w(int m2w)
 {
-    if (m2w == 1) return sat_sa_kernel<N1P, 1, QLDS, FAST, WPL>;
-    if (m2w == 2) return sat_sa_kernel<N1P, 2, QLDS, FAST, WPL>;
-    return sat_sa_kernel<N1P, 4, QLDS, FAST, WPL>;
+    if (m2w == 1) return sat_sa_kernel<N1P, 1, QLDS, OPT, WPL>;
+    if (m2w == 2) return sat_sa_kernel<N1P, 2, QLDS, OPT, WPL>;
+    return sat_sa_kernel<N1P, 4, QLDS, OPT, WPL>;
 }
 
-// fast = LORDER, no LSOLN, one lane per chain, compaction tables present, and every query of the
-// launch with the same words-per-lane `wpl` (see the kernel's FAST and WPL parameters).  The fast
-// instantiations exist for the default placement of the query cells only (LDS for the 16 class,
-// L1/L2 for the others) and for the wpl values the class can have (satk::compaction_shape).
-template <int N1P> kernel_fn pick_n1p(int m2w, bool qlds, bool fast, int wpl)
+// opt >= 0: an instantiation with the options as compile-time facts (bit 0 LORDER, bit 1 LSOLN; one
+// lane per chain, compaction tables exactly when LORDER); with LORDER also `wpl`, the words per
+// lane of the compacted rounds, which every query of the launch must share (see the kernel's OPT
+// and WPL parameters).  These exist for the default placement of the query cells only (LDS for the
+// 16 class, L1/L2 for the others) and for the wpl values a class can have
+// (satk::compaction_shape); anything else runs the general instantiation.
+template <int N1P, int OPT> kernel_fn pick_wpl(int m2w, int wpl)
 {
     constexpr bool kQ = N1P < 32;
-    if (fast && qlds == kQ) {
-        if (wpl == 4) return pick_m2w<N1P, kQ, true, 4>(m2w);
+    if constexpr ((OPT & 1) == 0) return pick_m2w<N1P, kQ, OPT, 0>(m2w);     // no compaction: wpl unused
+    else {
+        if (wpl == 4) return pick_m2w<N1P, kQ, OPT, 4>(m2w);
         if constexpr (N1P <= 64)
-            if (wpl == 3) return pick_m2w<N1P, kQ, true, 3>(m2w);
+            if (wpl == 3) return pick_m2w<N1P, kQ, OPT, 3>(m2w);
         if constexpr (N1P == 16) {
-            if (wpl == 2) return pick_m2w<N1P, kQ, true, 2>(m2w);
-            if (wpl == 1) return pick_m2w<N1P, kQ, true, 1>(m2w);
+            if (wpl == 2) return pick_m2w<N1P, kQ, OPT, 2>(m2w);
+            if (wpl == 1) return pick_m2w<N1P, kQ, OPT, 1>(m2w);
         }
+        return nullptr;
     }
-    return qlds ? pick_m2w<N1P, true, false, 0>(m2w) : pick_m2w<N1P, false, false, 0>(m2w);
 }
 
-kernel_fn pick_kernel(int n1p, int m2w, bool qlds, bool fast, int wpl)
+template <int N1P> kernel_fn pick_n1p(int m2w, bool qlds, int opt, int wpl)
+{
+    constexpr bool kQ = N1P < 32;
+    kernel_fn fn = nullptr;
+    if (opt >= 0 && qlds == kQ) {
+        switch (opt) {
+        case 0: fn = pick_wpl<N1P, 0>(m2w, wpl); break;
+        case 1: fn = pick_wpl<N1P, 1>(m2w, wpl); break;
+        case 2: fn = pick_wpl<N1P, 2>(m2w, wpl); break;
+        default: fn = pick_wpl<N1P, 3>(m2w, wpl); break;
+        }
+    }
+    if (fn) return fn;
+    return qlds ? pick_m2w<N1P, true, -1, 0>(m2w) : pick_m2w<N1P, false, -1, 0>(m2w);
+}
+
+kernel_fn pick_kernel(int n1p, int m2w, bool qlds, int opt, int wpl)
 {
     switch (n1p) {
-    case 16: return pick_n1p<16>(m2w, qlds, fast, wpl);
-    case 32: return pick_n1p<32>(m2w, qlds, fast, wpl);
-    case 64: return pick_n1p<64>(m2w, qlds, fast, wpl);
-    default: return pick_n1p<112>(m2w, qlds, fast, wpl);
+    case 16: return pick_n1p<16>(m2w, qlds, opt, wpl);
+    case 32: return pick_n1p<32>(m2w, qlds, opt, wpl);
+    case 64: return pick_n1p<64>(m2w, qlds, opt, wpl);
+    default: return pick_n1p<112>(m2w, qlds, opt, wpl);
     }
 }
 
@@ -325,8 +344,10 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             }
             a.lpc_shift = lpc_shift;
             a.compact = compact ? 1 : 0;
-            const bool fast = lorder != 0 && lsoln == 0 && lpc_shift == 0 && compact && !getenv("SAT_EXP_GENERAL");
-            kernel_fn fn = pick_kernel(n1p, m2w, qlds, fast, ctx->class_wpl[c]);
+            // option-specialised instantiation when the layout is the default one for these options
+            const bool special = lpc_shift == 0 && compact == (lorder != 0) && !getenv("SAT_EXP_GENERAL");
+            const int opt = special ? (lorder ? 1 : 0) | (lsoln ? 2 : 0) : -1;
+            kernel_fn fn = pick_kernel(n1p, m2w, qlds, opt, ctx->class_wpl[c]);
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));

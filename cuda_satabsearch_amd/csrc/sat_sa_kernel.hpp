@@ -388,12 +388,13 @@ __device__ __forceinline__ void perturb(uint32_t (&d)[4])
 
 // N1P: pitch of the query cell matrix (>= 4*ceil(n1/4)); M2W: 32-bit words of a db-side
 // bit set (n2 <= 32*M2W); QLDS: query cells staged in LDS (else read through L1/L2).
-// FAST: the options of a plain search are compile-time facts (LORDER = T, LSOLN = F, one lane
-// per chain, work compaction available); the host launches such an instantiation when they hold
-// and the general one otherwise.  Same code, but the option tests leave the SA step loop.
+// OPT: -1 = every option is read from the arguments (the general instantiation: several lanes
+// per chain, forced layouts); otherwise the options are compile-time facts - bit 0 LORDER, bit 1
+// LSOLN, one lane per chain, work compaction exactly when LORDER - and their tests leave the SA
+// step loop (the general kernel spills ~90 SGPRs and is ~9 % slower on the bench shape).
 // WPL: map words per lane in the compacted rounds (satk::compaction_shape) when every query of
 // the launch has the same; 0 = read it from the query (a four-way switch per step).
-template <int N1P, int M2W, bool QLDS, bool FAST, int WPL>
+template <int N1P, int M2W, bool QLDS, int OPT, int WPL>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
 sat_sa_kernel(const SatKernelArgs a)
 {
@@ -404,9 +405,10 @@ sat_sa_kernel(const SatKernelArgs a)
     const int lane_id = threadIdx.x;
     const int nthreads = blockDim.x;
     // chain = restart slot of this lane; `part` of `lpc` adjacent lanes share one chain
+    constexpr bool FAST = OPT >= 0;
     const int lpc_shift = FAST ? 0 : a.lpc_shift;
-    const bool opt_lorder = FAST ? true : a.lorder != 0;
-    const bool opt_compact = FAST ? true : a.compact != 0;
+    const bool opt_lorder = FAST ? (OPT & 1) != 0 : a.lorder != 0;
+    const bool opt_compact = FAST ? (OPT & 1) != 0 : a.compact != 0;
     const int lpc = 1 << lpc_shift;
     const int tid = lane_id >> lpc_shift;         // chain index inside the workgroup
     const int part = lane_id & (lpc - 1);
@@ -419,7 +421,7 @@ sat_sa_kernel(const SatKernelArgs a)
     const int n2p = n2 + 1;
     const int n1w = (n1 + 3) >> 2;
     const int NULLJ = n2;                       // the null db SSE
-    const bool lsoln = FAST ? false : a.lsoln != 0;
+    const bool lsoln = FAST ? (OPT & 2) != 0 : a.lsoln != 0;
 
     // ---- carve LDS (must match satk::lds_bytes)
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
