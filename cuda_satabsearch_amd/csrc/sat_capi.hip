@@ -129,8 +129,8 @@ template <int N1P, bool QLDS, int OPT, int WPL> kernel_fn pick_m2w(int m2w)
 
 // opt >= 0: an instantiation with the options as compile-time facts (bit 0 LORDER, bit 1 LSOLN; one
 // lane per chain, compaction tables exactly when LORDER); with LORDER also `wpl`, the words per
-// lane of the compacted rounds, which every query of the launch must share (see the kernel's OPT
-// and WPL parameters).  These exist for the default placement of the query cells only (LDS for the
+// lane of the compacted rounds when every query of the launch has the same, else 0 (see the
+// kernel's OPT and WPL parameters).  These exist for the default placement of the query cells only (LDS for the
 // 16 class, L1/L2 for the others) and for the wpl values a class can have
 // (satk::compaction_shape); anything else runs the general instantiation.
 template <int N1P, int OPT> kernel_fn pick_wpl(int m2w, int wpl)
@@ -145,7 +145,7 @@ template <int N1P, int OPT> kernel_fn pick_wpl(int m2w, int wpl)
             if (wpl == 2) return pick_m2w<N1P, kQ, OPT, 2>(m2w);
             if (wpl == 1) return pick_m2w<N1P, kQ, OPT, 1>(m2w);
         }
-        return nullptr;
+        return pick_m2w<N1P, kQ, OPT, 0>(m2w);       // queries of different shapes: wpl read per query
     }
 }
 

@@ -395,7 +395,7 @@ __device__ __forceinline__ void perturb(uint32_t (&d)[4])
 // WPL: map words per lane in the compacted rounds (satk::compaction_shape) when every query of
 // the launch has the same; 0 = read it from the query (a four-way switch per step).
 template <int N1P, int M2W, bool QLDS, int OPT, int WPL>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(OPT < 0 ? 4 : 6)))
 sat_sa_kernel(const SatKernelArgs a)
 {
     using namespace satk;
