@@ -89,9 +89,12 @@ int build_metropolis_table(sat_ctx *ctx)
         }
         rows[2 * it] = (int32_t)tab.size();
         rows[2 * it + 1] = last;
-        // stored times 2^32 (exact): the kernel compares with 2^32 * u
+        // stored times 2^32 (exact): the kernel compares with 2^32 * u.  The row is indexed by
+        // 1 - delta clamped to [0, last + 2]: a leading 2^33 for every delta > 0 (expf(x > 0) > 1 >= u)
+        // and a trailing 0.0 for "can never be accepted"
+        tab.push_back(8589934592.0f);
         for (int nd = 0; nd <= last; nd++) tab.push_back(ldexpf(row[nd], 32));
-        tab.push_back(0.0f);                         // entry last + 1: "can never be accepted"
+        tab.push_back(0.0f);
         temp = temp * 0.95f;
     }
     HIP_TRY(hipMalloc(&ctx->d_ptab, tab.size() * sizeof(float)));

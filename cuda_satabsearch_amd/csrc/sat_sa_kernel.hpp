@@ -122,7 +122,7 @@ struct SatKernelArgs {
     uint32_t       *bmap_slabs;   // LSOLN: best-map slab of workgroup g at g * bmap_slab_words
     uint32_t        bmap_slab_words;
     // Metropolis table
-    const float    *ptab;         // ragged rows of 2^32 * expf(-nd / temp)
+    const float    *ptab;         // ragged rows { 2^33, 2^32 * expf(-nd / temp) for nd = 0 .. last, 0.0 }
     const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
 #ifdef SAT_PHASE_TIMING
     unsigned long long *phase;    // [8] wave-cycles per SA-step phase (diagnostic builds only, scripts/exp/variant_lib.sh)
@@ -416,7 +416,9 @@ sat_sa_kernel(const SatKernelArgs a)
     const int e = a.entry_list[blockIdx.x];
     const SatQuery Q = a.queries[blockIdx.y];
     const int n1 = Q.n1;
-    const double n1d = (double)n1;
+    // (double)n1 kept in scalar registers: as a plain value the compiler converts it again every step
+    const double n1d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint((double)n1)),
+                                        __builtin_amdgcn_readfirstlane(__double2loint((double)n1)));
     const int n2 = a.orders[e];
     const int n2p = n2 + 1;
     const int n1w = (n1 + 3) >> 2;
@@ -460,6 +462,8 @@ sat_sa_kernel(const SatKernelArgs a)
     typedef const __attribute__((address_space(1))) char *gptr_c;
     typedef const __attribute__((address_space(4))) int32_t *cptr_i32;
     const cptr_i32 prowC = (cptr_i32)(uintptr_t)a.prow;
+    typedef const __attribute__((address_space(1))) float *gptr_f32;
+    const gptr_f32 ptabG = (gptr_f32)(uintptr_t)a.ptab;
     // uniform 64-bit base + 32-bit byte offset: the saddr form of global_load, no 64-bit VALU math
     auto load_qdist = [&](uint32_t idx) -> float4 {
         if constexpr (QLDS) return qdistL[idx];
@@ -602,9 +606,9 @@ sat_sa_kernel(const SatKernelArgs a)
         }
         if (lpc >= 2) score += __shfl_xor(score, 1, 64);
         if (lpc == 4) score += __shfl_xor(score, 2, 64);
+        const int best_before = best;
         if (score > best) {
             best = score;
-            best_restart = (uint32_t)restart;
             if (lsoln)
                 for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
         }
@@ -694,22 +698,23 @@ sat_sa_kernel(const SatKernelArgs a)
                 uint32_t c = cand.w[0];
                 int left = pick;
                 while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
-                    const bool go = left > 0;
-                    c = go ? (c & (c - 1u)) : c;
-                    left -= go ? 1 : 0;
+                    const uint32_t go = left > 0 ? 1u : 0u;
+                    c &= c - go;                                   // c & (c - 1) clears the lowest set bit
+                    left -= (int)go;
                 }
                 sel = __ffs(c) - 1;
             } else {
                 sel = bits_select<M2W>(cand, pick);
             }
-            const int newj = cnt == 0 ? NULLJ : sel;
+            const bool nreal = cnt != 0;
+            const int newj = nreal ? sel : NULLJ;
 
             SAT_PHASE(0);                 // draw + proposal
             // score change (deltasd, K.cu:502-535)
             int delta;
             {
                 // rows of this step that are real, listed once per chain (part 0 of its lanes)
-                const bool oreal = oldj != NULLJ, nreal = newj != NULLJ;
+                const bool oreal = oldj != NULLJ;
                 const bool lists = part == 0;
                 const int nitems = lists ? (int)oreal + (int)nreal : 0;
                 const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lists && (oreal || nreal)),
@@ -829,23 +834,21 @@ sat_sa_kernel(const SatKernelArgs a)
             SAT_PHASE(3);                 // read-back (compacted) or the static loops
 
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
-            if (newscore > best) {
-                best = newscore;
-                best_restart = (uint32_t)restart;
-                if (lsoln) {
-                    for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
-                    bmap_b[bmap_byte_addr(ssei)] = (uint8_t)newj;
-                }
+            // (which restart holds the best is settled once per restart, below the step loop)
+            if (lsoln && newscore > best) {
+                for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
+                bmap_b[bmap_byte_addr(ssei)] = (uint8_t)newj;
             }
+            best = max(best, newscore);
 
             SAT_PHASE(4);                 // best tracking
             // Metropolis: accept iff expf(delta / temp) > u, via the host-built table
             // the table holds 2^32 * expf(.), compared with 2^32 * u: same decision, one multiply less
             const float u = draw32(r.z);
-            // entry rowmax + 1 of every row is 0.0: larger -delta can never be accepted
-            const int nd = min(max(-delta, 0), rowmax + 1);
-            const float ptable = a.ptab[rowoff + nd];
-            const float p = delta > 0 ? 8589934592.0f : ptable;   // expf(x > 0) > 1 >= u
+            // row = { 2^33 (any delta > 0: expf(x > 0) > 1 >= u), P[0], ..., P[rowmax], 0.0 (a larger
+            // -delta can never be accepted) }, indexed by 1 - delta clamped to the row
+            const uint32_t nd = (uint32_t)min(max(1 - delta, 0), rowmax + 2);
+            const float p = *(gptr_f32)((gptr_c)ptabG + (((uint32_t)rowoff + nd) << 2));
             const bool accept = p > u;
             if (accept) smap_b[map_byte_addr(ssei)] = (uint8_t)newj;
             score = accept ? newscore : score;
@@ -853,17 +856,21 @@ sat_sa_kernel(const SatKernelArgs a)
                 Bits<M2W> occ2 = occ;
                 Bits<M1W> mapped2 = mapped;
                 if constexpr (M2W == 1) {
-                    // bit n2 (the null SSE) must not be touched; n2 may be 32: mask by comparison
-                    const uint32_t oldbit = oldj != NULLJ ? (1u << (oldj & 31)) : 0u;
-                    const uint32_t newbit = newj != NULLJ ? (1u << (newj & 31)) : 0u;
-                    occ2.w[0] = (occ.w[0] & ~oldbit) | newbit;
+                    // bit n2 (the null SSE) must not be touched; n2 may be 32: mask by comparison.
+                    // The accept decision is folded into the masks (scalar AND of lane masks).
+                    const uint32_t oldbit = (accept && oldj != NULLJ) ? (1u << (oldj & 31)) : 0u;
+                    const uint32_t newbit = (accept && nreal) ? (1u << (newj & 31)) : 0u;
+                    occ.w[0] = (occ.w[0] & ~oldbit) | newbit;
+                    occ2 = occ;
                 } else {
                     if (oldj != NULLJ) bits_clear<M2W>(occ2, oldj);
                     if (newj != NULLJ) bits_set<M2W>(occ2, newj);
                 }
                 if constexpr (M1W == 1) {
                     const uint32_t ibit = 1u << ssei;
-                    mapped2.w[0] = newj != NULLJ ? (mapped.w[0] | ibit) : (mapped.w[0] & ~ibit);
+                    const uint32_t setbit = (accept && nreal) ? ibit : 0u, clrbit = (accept && !nreal) ? ibit : 0u;
+                    mapped.w[0] = (mapped.w[0] & ~clrbit) | setbit;
+                    mapped2 = mapped;
                 } else {
                     if (newj != NULLJ) bits_set<M1W>(mapped2, ssei);
                     else bits_clear<M1W>(mapped2, ssei);
@@ -875,6 +882,7 @@ sat_sa_kernel(const SatKernelArgs a)
             }
             SAT_PHASE(5);                 // Metropolis + state update
         }
+        if (best > best_before) best_restart = (uint32_t)restart;
     }
     SAT_PHASE_FLUSH;
 #ifdef SAT_EXP_PERTURB
