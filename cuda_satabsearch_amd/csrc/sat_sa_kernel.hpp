@@ -717,8 +717,11 @@ sat_sa_kernel(const SatKernelArgs a)
                 const bool oreal = oldj != NULLJ;
                 const bool lists = part == 0;
                 const int nitems = lists ? (int)oreal + (int)nreal : 0;
-                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lists && (oreal || nreal)),
-                                         m2 = __builtin_amdgcn_ballot_w64(lists && oreal && nreal);
+                // (two plain ballots and scalar logic: a ballot of a combined predicate goes through
+                // a select and a compare per lane)
+                const unsigned long long bo = __builtin_amdgcn_ballot_w64(lists && oreal),
+                                         bn = __builtin_amdgcn_ballot_w64(lists && nreal);
+                const unsigned long long m1 = bo | bn, m2 = bo & bn;
                 const int total_items = __popcll(m1) + __popcll(m2);           // wave-uniform
                 // only full waves compact (a wave's last lanes may have no restart left), so a lane's
                 // rank among the consumers is its lane number; see cmp_* above the restart loop
