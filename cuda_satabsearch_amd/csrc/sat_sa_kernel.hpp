@@ -476,6 +476,23 @@ sat_sa_kernel(const SatKernelArgs a)
         if constexpr (QLDS) return qcodeL[idx];
         else return *(gptr_u32)((gptr_c)qcodeG + (idx << 2));
     };
+    // the same cells for a wave-uniform index (the full score walks the query in step for all
+    // chains): through the constant address space these are scalar loads into scalar registers
+    typedef const __attribute__((address_space(4))) f32x4_t *cptr_f4;
+    typedef const __attribute__((address_space(4))) uint32_t *cptr_u32;
+    const cptr_f4 qdistC = (cptr_f4)(uintptr_t)Q.qdist;
+    const cptr_u32 qcodeC = (cptr_u32)(uintptr_t)Q.qcode;
+    auto load_qdist_uniform = [&](uint32_t idx) -> float4 {
+        if constexpr (QLDS) return qdistL[idx];
+        else {
+            const f32x4_t v = qdistC[idx];
+            return float4{ v.x, v.y, v.z, v.w };
+        }
+    };
+    auto load_qcode_uniform = [&](uint32_t idx) -> uint32_t {
+        if constexpr (QLDS) return qcodeL[idx];
+        else return qcodeC[idx];
+    };
 
     // ---- stage the db entry: packed lower triangle (HBM) -> full cell matrix (LDS)
     {
@@ -600,9 +617,17 @@ sat_sa_kernel(const SatKernelArgs a)
                 const uint32_t qi = (uint32_t)(kw * N1P + i);
                 score = quad_terms(load_qdist(qi), load_qcode(qi), drow, smap[kw * TP + tid], force, score);
             };
-            // one lane per chain: the group index stays in scalar registers
-            if (lpc == 1) for (int kw = (i + 1) >> 2; kw < n1w; kw++) row_group(kw);
-            else for (int kw = ((i + 1) >> 2) + part; kw < n1w; kw += lpc) row_group(kw);
+            // one lane per chain: the group index stays in scalar registers, and so do the query cells
+            if (lpc == 1) {
+                for (int kw = (i + 1) >> 2; kw < n1w; kw++) {
+                    const int below = i + 1 - 4 * kw;
+                    const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
+                    const uint32_t qi = (uint32_t)(kw * N1P + i);
+                    score = quad_terms(load_qdist_uniform(qi), load_qcode_uniform(qi), drow, smap[kw * TP + tid], force, score);
+                }
+            } else {
+                for (int kw = ((i + 1) >> 2) + part; kw < n1w; kw += lpc) row_group(kw);
+            }
         }
         if (lpc >= 2) score += __shfl_xor(score, 1, 64);
         if (lpc == 4) score += __shfl_xor(score, 2, 64);
