@@ -15,7 +15,8 @@
  * exit() or abort().  Environment (tuning / test overrides of launch heuristics, results do
  * not depend on them): SAT_EXP_LPC = 0|1|2 (log2 lanes per chain), SAT_EXP_COMPACT = 0|1
  * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS),
- * SAT_EXP_LDS_PAD = bytes (unused LDS added per workgroup: occupancy experiments).
+ * SAT_EXP_LDS_PAD = bytes (unused LDS added per workgroup: occupancy experiments),
+ * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones).
  * There is no CPU fallback: without a usable HIP device sat_ctx_create() fails with
  * SAT_ENODEVICE.
  */
