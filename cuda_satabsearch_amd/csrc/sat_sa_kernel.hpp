@@ -331,7 +331,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
     dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
     size_t bytes = dcells * 8;
-    if (q_in_lds) bytes += n1w * (size_t)n1p * 20;            // float4 + code dword per (group, column)
+    if (q_in_lds) bytes += (size_t)map_words((int)n1w) * (size_t)n1p * 20;   // float4 + code dword per (group, column)
     bytes += (size_t)map_words((int)n1w) * (chains + 1) * 4;  // map words (padded), row stride chains + 1 (bank skew)
     (void)lsoln;                                              // the best maps live in global memory
     bytes += 16 * 4;                                          // tmask[4][<=4]
@@ -429,17 +429,18 @@ sat_sa_kernel(const SatKernelArgs a)
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
     dcells = (dcells + 1) & ~(size_t)1;
     uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);
-    float4 *qdistL = reinterpret_cast<float4 *>(Dc + dcells);
-    uint32_t *qcodeL = reinterpret_cast<uint32_t *>(qdistL + (QLDS ? (size_t)n1w * N1P : 0));
-    uint32_t *smap = qcodeL + (QLDS ? (size_t)n1w * N1P : 0);
-    // map word w of chain c lives at w*TP + c with TP = T + 1: the odd stride puts the words of
-    // one chain in different banks (the compacted loop reads them from n1w lanes at once) and
-    // keeps word w of all chains contiguous for the static loops
-    const int TP = T + 1;
     int cmp_lpi, cmp_wpl_q;
     compaction_shape(n1w, cmp_lpi, cmp_wpl_q);
     const int cmp_wpl = WPL > 0 ? WPL : cmp_wpl_q;           // the host launches WPL > 0 only where it matches
     const int cmp_words = cmp_lpi * cmp_wpl;                 // words n1w .. cmp_words - 1 stay "unmatched"
+    // query groups in LDS cover the padding words too (sentinel cells, like every group past n1w)
+    float4 *qdistL = reinterpret_cast<float4 *>(Dc + dcells);
+    uint32_t *qcodeL = reinterpret_cast<uint32_t *>(qdistL + (QLDS ? (size_t)cmp_words * N1P : 0));
+    uint32_t *smap = qcodeL + (QLDS ? (size_t)cmp_words * N1P : 0);
+    // map word w of chain c lives at w*TP + c with TP = T + 1: the odd stride puts the words of
+    // one chain in different banks (the compacted loop reads them from several lanes at once) and
+    // keeps word w of all chains contiguous for the static loops
+    const int TP = T + 1;
     uint32_t *tmask = smap + (size_t)cmp_words * TP;
     // best maps: word w of chain c at w*T + c of this workgroup's slab (global memory)
     uint32_t *bmap = lsoln ? a.bmap_slabs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.bmap_slab_words : nullptr;
@@ -519,7 +520,7 @@ sat_sa_kernel(const SatKernelArgs a)
         if (lane_id < 16) tmask[lane_id] = 0u;
         for (int i = lane_id; i < N1P; i += nthreads) qtypes[i] = Q.qtypes[i];
         if (QLDS) {
-            const int groups = n1w * N1P;
+            const int groups = cmp_words * N1P;
             for (int c = lane_id; c < groups; c += nthreads) {
                 qdistL[c] = Q.qdist[c];
                 qcodeL[c] = Q.qcode[c];
