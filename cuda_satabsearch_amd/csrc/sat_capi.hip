@@ -321,18 +321,21 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                 }
                 return fail(SAT_EINVAL, "workgroup does not fit in LDS (n1=%d n2=%d)", n1max, n2max);
             }
-            // lanes per chain: when LDS leaves fewer than ~3 waves per SIMD, let 2 or 4 adjacent
-            // lanes share a chain (same LDS, 2-4x the waves; they split the pair loops)
+            // lanes per chain: when LDS leaves fewer than 2 waves per SIMD, let 2 or 4 adjacent lanes
+            // share a chain (same cells in LDS, 2-4x the waves; they split the pair loops).  Measured:
+            // the smallest sharing that reaches 8 waves per CU wins (one lane per chain also runs the
+            // option-specialised kernels); beyond that, sharing only adds redundant bookkeeping.
             int lpc_shift = 0;
-            {
-                const int wgs = (int)(kLdsLimit / lds);
-                while (lpc_shift < 2 && wgs * ((chains << lpc_shift) / 64) < 12 && (chains << (lpc_shift + 1)) <= 1024 &&
-                       n1max > (8 << lpc_shift))
-                    lpc_shift++;
-                if (const char *ov = getenv("SAT_EXP_LPC")) {
-                    int v = atoi(ov);
-                    if (v >= 0 && v <= 2 && (chains << v) <= 1024) lpc_shift = v;
-                }
+            for (int l = 0; l <= 2; l++) {
+                if ((chains << l) > 1024 || (l > 0 && n1max <= (8 << (l - 1)))) break;
+                const size_t lds_l = satk::lds_bytes(n1max, n1p, n2max, chains, chains << l, lsoln != 0, qlds, compact);
+                if (lds_l > kLdsLimit) break;
+                lpc_shift = l;
+                if ((int)(kLdsLimit / lds_l) * ((chains << l) / 64) >= 8) break;
+            }
+            if (const char *ov = getenv("SAT_EXP_LPC")) {
+                int v = atoi(ov);
+                if (v >= 0 && v <= 2 && (chains << v) <= 1024) lpc_shift = v;
             }
             // the per-wave tables grow with the lanes: re-size, backing off if that no longer fits
             for (;; lpc_shift--) {
