@@ -247,7 +247,7 @@ def main():
             "scorings_per_sec_incl_upload_single_query": total / (elapsed / args.steps + upload_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sat_sa_kernel<32,1,false>", "kernel_ms_avg": kavg_ms,
+                         "kernel": "sat_sa_kernel<32,1,false,1,4>", "kernel_ms_avg": kavg_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "nominal bound only: 2648 B per scoring against 12 800 dependent SA steps; "
                                  "the kernel is VALU/LDS-issue bound (DESIGN.md section 4)"},
