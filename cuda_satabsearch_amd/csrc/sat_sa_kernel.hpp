@@ -332,11 +332,13 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
     size_t bytes = dcells * 8;
     if (q_in_lds) bytes += (size_t)map_words((int)n1w) * (size_t)n1p * 20;   // float4 + code dword per (group, column)
-    bytes += (size_t)map_words((int)n1w) * (chains + 1) * 4;  // map words (padded), row stride chains + 1 (bank skew)
+    // map words (padded), row stride chains + 1 (bank skew); an even word count keeps what follows
+    // 8-byte aligned (the 64-bit reduction keys and the LSOLN leader key, an LDS atomic)
+    bytes += (((size_t)map_words((int)n1w) * (chains + 1) + 1) & ~(size_t)1) * 4;
     (void)lsoln;                                              // the best maps live in global memory
     bytes += 16 * 4;                                          // tmask[4][<=4]
     bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
-    bytes += 16 * 8;                                          // reduction scratch (<= 16 waves)
+    bytes += 17 * 8;                                          // reduction scratch (<= 16 waves) + LSOLN leader key
     if (compact) {
         bytes += (size_t)((threads + 63) / 64) * 64 * 4;      // per-wave item table (compaction handles <= 64 rows)
     }
@@ -441,7 +443,7 @@ sat_sa_kernel(const SatKernelArgs a)
     // one chain in different banks (the compacted loop reads them from several lanes at once) and
     // keeps word w of all chains contiguous for the static loops
     const int TP = T + 1;
-    uint32_t *tmask = smap + (size_t)cmp_words * TP;
+    uint32_t *tmask = smap + ((((size_t)cmp_words * TP) + 1) & ~(size_t)1);   // even: keeps `red` 8-byte aligned
     // best maps: word w of chain c at w*T + c of this workgroup's slab (global memory)
     uint32_t *bmap = lsoln ? a.bmap_slabs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.bmap_slab_words : nullptr;
     uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
@@ -450,7 +452,20 @@ sat_sa_kernel(const SatKernelArgs a)
     // same wave between wavefront-scope fences, and must stay ds_* instructions
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     typedef __attribute__((address_space(3))) int32_t lds_i32_t;
-    const uint32_t items_off = (uint32_t)(reinterpret_cast<unsigned char *>(red + 16) - lds_raw);
+    const uint32_t items_off = (uint32_t)(reinterpret_cast<unsigned char *>(red + 17) - lds_raw);
+    // LSOLN: key (score, restart) of the best proposal any chain of the workgroup has recorded so
+    // far, same form as the final arg-max key.  A chain copies its map out only when its new best
+    // beats this leader: the map that is finally output belongs to the chain with the largest key,
+    // and that chain's last own-best proposal always beats every key recorded before it (a stale,
+    // lower leader only causes a spare copy).  ~1150 copies per workgroup become ~20.
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+    lds_u64_t *leader = (lds_u64_t *)(uintptr_t)(uint32_t)(reinterpret_cast<unsigned char *>(red + 16) - lds_raw);
+    auto beats_leader = [&](int sc, int restart_) -> bool {
+        const unsigned long long key = (((unsigned long long)(uint32_t)(sc + 0x40000000)) << 32) | (0xFFFFFFFFu - (uint32_t)restart_);
+        if (key <= *leader) return false;
+        __hip_atomic_fetch_max(leader, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return true;
+    };
     lds_u32_t *items = (lds_u32_t *)(uintptr_t)(uint32_t)(items_off + (uint32_t)(lane_id >> 6) * 256u);
     // query group (4 distances, 4 code bytes) of column `col`: from LDS, or from global memory
     // through L1 - the descriptor's pointers are cast to the global address space so that the
@@ -518,6 +533,7 @@ sat_sa_kernel(const SatKernelArgs a)
             Dc[c] = cell;
         }
         if (lane_id < 16) tmask[lane_id] = 0u;
+        if (lane_id == 0) red[16] = 0ull;                     // LSOLN leader key
         for (int i = lane_id; i < N1P; i += nthreads) qtypes[i] = Q.qtypes[i];
         if (QLDS) {
             const int groups = cmp_words * N1P;
@@ -635,7 +651,7 @@ sat_sa_kernel(const SatKernelArgs a)
         const int best_before = best;
         if (score > best) {
             best = score;
-            if (lsoln)
+            if (lsoln && beats_leader(score, restart))
                 for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
         }
 
@@ -865,8 +881,10 @@ sat_sa_kernel(const SatKernelArgs a)
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
             // (which restart holds the best is settled once per restart, below the step loop)
             if (lsoln && newscore > best) {
-                for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
-                bmap_b[bmap_byte_addr(ssei)] = (uint8_t)newj;
+                if (beats_leader(newscore, restart)) {
+                    for (int w = 0; w < n1w; w++) bmap[w * T + tid] = smap[w * TP + tid];
+                    bmap_b[bmap_byte_addr(ssei)] = (uint8_t)newj;
+                }
             }
             best = max(best, newscore);
 
