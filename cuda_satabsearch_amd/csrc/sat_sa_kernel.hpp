@@ -234,13 +234,31 @@ template <int W> __device__ __forceinline__ int bits_select(const Bits<W> &b, in
 //   qd, qc   the query group's distances and code bytes for this lane's column
 //   force    0x04 in byte s forces pair s to score 0 (used by the full score for k <= i)
 // Returns acc + sum.  See the file header for the arithmetic.
-__device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const uint2 *row,
+// A row of the db entry's cell matrix in LDS.  Entries of up to 32 SSEs keep 8-byte cells
+// {f32 distance, code byte}: one ds_read_b64 per pair.  Larger entries keep the distances and the
+// code bytes in two arrays (5 bytes per cell, two reads per pair): their cells are what limits the
+// workgroups per CU, and 37 % less LDS is worth more there than the extra reads.
+template <bool SPLIT> struct DbRow;
+template <> struct DbRow<false> { const uint2 *cells; };
+template <> struct DbRow<true> { const float *dist; const uint8_t *code; };
+
+template <bool SPLIT>
+__device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const DbRow<SPLIT> row,
                                           const uint32_t word, const uint32_t force, const int acc)
 {
-    const uint2 d0 = row[word & 0xFFu];
-    const uint2 d1 = row[(word >> 8) & 0xFFu];
-    const uint2 d2 = row[(word >> 16) & 0xFFu];
-    const uint2 d3 = row[word >> 24];
+    const uint32_t l0 = word & 0xFFu, l1 = (word >> 8) & 0xFFu, l2 = (word >> 16) & 0xFFu, l3 = word >> 24;
+    uint2 d0, d1, d2, d3;
+    if constexpr (SPLIT) {
+        d0 = uint2{ __float_as_uint(row.dist[l0]), row.code[l0] };
+        d1 = uint2{ __float_as_uint(row.dist[l1]), row.code[l1] };
+        d2 = uint2{ __float_as_uint(row.dist[l2]), row.code[l2] };
+        d3 = uint2{ __float_as_uint(row.dist[l3]), row.code[l3] };
+    } else {
+        d0 = row.cells[l0];
+        d1 = row.cells[l1];
+        d2 = row.cells[l2];
+        d3 = row.cells[l3];
+    }
     // sign bit of t = "distances differ by more than 4 A"
     const float t0 = 4.0f - fabsf(qd.x - __uint_as_float(d0.x));
     const float t1 = 4.0f - fabsf(qd.y - __uint_as_float(d1.x));
@@ -329,8 +347,14 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
 {
     size_t n1w = (size_t)((n1 + 3) >> 2);
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
-    dcells = (dcells + 1) & ~(size_t)1;                       // keep 16-byte alignment
-    size_t bytes = dcells * 8;
+    size_t bytes;
+    if (n2 > 32) {                                            // split cells (see DbRow), both arrays 16-byte multiples
+        dcells = (dcells + 3) & ~(size_t)3;
+        bytes = dcells * 4 + ((dcells + 15) & ~(size_t)15);
+    } else {
+        dcells = (dcells + 1) & ~(size_t)1;                   // keep 16-byte alignment
+        bytes = dcells * 8;
+    }
     if (q_in_lds) bytes += (size_t)map_words((int)n1w) * (size_t)n1p * 20;   // float4 + code dword per (group, column)
     // map words (padded), row stride chains + 1 (bank skew); an even word count keeps what follows
     // 8-byte aligned (the 64-bit reduction keys and the LSOLN leader key, an LDS atomic)
@@ -428,15 +452,25 @@ sat_sa_kernel(const SatKernelArgs a)
     const bool lsoln = FAST ? (OPT & 2) != 0 : a.lsoln != 0;
 
     // ---- carve LDS (must match satk::lds_bytes)
+    // cell layout by the launch's size class, not by this entry's order (satk::lds_bytes sizes the
+    // workgroup for the largest entry of the launch with the same rule: n2max > 32 <=> M2W > 1)
+    constexpr bool SPLIT = M2W > 1;
     size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
-    dcells = (dcells + 1) & ~(size_t)1;
-    uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);
+    dcells = SPLIT ? (dcells + 3) & ~(size_t)3 : (dcells + 1) & ~(size_t)1;
+    uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);                          // !SPLIT: 8-byte cells
+    float *distL = reinterpret_cast<float *>(lds_raw);                       // SPLIT: distances ...
+    uint8_t *codeL = reinterpret_cast<uint8_t *>(distL + dcells);           // ... and code bytes
+    unsigned char *after_cells = SPLIT ? codeL + ((dcells + 15) & ~(size_t)15) : reinterpret_cast<unsigned char *>(Dc + dcells);
+    auto db_row = [&](int j) -> DbRow<SPLIT> {
+        if constexpr (SPLIT) return DbRow<true>{ distL + __mul24(j, n2p), codeL + __mul24(j, n2p) };
+        else return DbRow<false>{ Dc + __mul24(j, n2p) };
+    };
     int cmp_lpi, cmp_wpl_q;
     compaction_shape(n1w, cmp_lpi, cmp_wpl_q);
     const int cmp_wpl = WPL > 0 ? WPL : cmp_wpl_q;           // the host launches WPL > 0 only where it matches
     const int cmp_words = cmp_lpi * cmp_wpl;                 // words n1w .. cmp_words - 1 stay "unmatched"
     // query groups in LDS cover the padding words too (sentinel cells, like every group past n1w)
-    float4 *qdistL = reinterpret_cast<float4 *>(Dc + dcells);
+    float4 *qdistL = reinterpret_cast<float4 *>(after_cells);
     uint32_t *qcodeL = reinterpret_cast<uint32_t *>(qdistL + (QLDS ? (size_t)cmp_words * N1P : 0));
     uint32_t *smap = qcodeL + (QLDS ? (size_t)cmp_words * N1P : 0);
     // map word w of chain c lives at w*TP + c with TP = T + 1: the odd stride puts the words of
@@ -530,7 +564,12 @@ sat_sa_kernel(const SatKernelArgs a)
                 cell.x = __float_as_uint(SAT_K_DSENT);   // the null SSE never passes the distance test
                 cell.y = 0u;
             }
-            Dc[c] = cell;
+            if constexpr (SPLIT) {
+                distL[c] = __uint_as_float(cell.x);
+                codeL[c] = (uint8_t)cell.y;
+            } else {
+                Dc[c] = cell;
+            }
         }
         if (lane_id < 16) tmask[lane_id] = 0u;
         if (lane_id == 0) red[16] = 0ull;                     // LSOLN leader key
@@ -626,7 +665,7 @@ sat_sa_kernel(const SatKernelArgs a)
         int score = 0;
         for (int i = 0; i < n1 - 1; i++) {
             const int j = smap_b[map_byte_addr(i)];
-            const uint2 *drow = Dc + __mul24(j, n2p);
+            const DbRow<SPLIT> drow = db_row(j);
             auto row_group = [&](int kw) {
                 // pairs with k <= i inside the first word are switched off (mask from i and kw)
                 const int below = i + 1 - 4 * kw;
@@ -792,7 +831,7 @@ sat_sa_kernel(const SatKernelArgs a)
                         if (ok) {
                             const uint32_t it = items[idx];
                             const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
-                            const uint2 *drow = Dc + __mul24(row, n2p);
+                            const DbRow<SPLIT> drow = db_row(row);
                             float4 qd[W];
                             uint32_t qc[W], wd[W];
 #pragma unroll
@@ -857,8 +896,7 @@ sat_sa_kernel(const SatKernelArgs a)
                     if (lpc > 1) delta = __shfl(delta, (lane_id & 63) & ~(lpc - 1), 64);
                 } else {
                     // dense regime: every lane scores its own two rows
-                    const uint2 *orow = Dc + __mul24(oldj, n2p);
-                    const uint2 *nrow = Dc + __mul24(newj, n2p);
+                    const DbRow<SPLIT> orow = db_row(oldj), nrow = db_row(newj);
                     int sum_new = 0, sum_old = 0;
                     auto move_group = [&](int kw) {
                         const uint32_t word = smap[kw * TP + tid];
