@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "satabsearch.h"
@@ -485,29 +486,72 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
     if (!ctx) return fail(SAT_EINVAL, "null context");
     if (n_entries <= 0 || !orders || !cell_off || !tab_tri || !dist_tri)
         return fail(SAT_EINVAL, "empty database or null array");
+    // header pass (orders, offsets, ordinals), then the cells: a scan of every code byte and
+    // distance, which is a memory-bound read of the whole database (331 MB for the bench shard) -
+    // split over a few host threads, each looking for its first bad entry with branch-free row
+    // reductions; the earliest one is then re-checked cell by cell for the message.
     int64_t cells_end = 0;
     for (int e = 0; e < n_entries; e++) {
         const int n = orders[e];
         if (n < 1 || n > SAT_MAXDIM)
             return fail(SAT_EINVAL, "entry %d: order %d outside 1..%d", e, n, SAT_MAXDIM);
         if (cell_off[e] < 0) return fail(SAT_EINVAL, "entry %d: negative cell offset", e);
-        for (int i = 0; i < n; i++) {
-            const int64_t rowbase = cell_off[e] + (int64_t)i * (i + 1) / 2;
-            uint8_t t = tab_tri[rowbase + i];
-            if (t > 3) return fail(SAT_EINVAL, "entry %d: SSE %d has type code %u (0..3 expected)", e, i, t);
-            for (int j = 0; j < i; j++) {
-                // the packed pair arithmetic needs nibbles 0..7 (the reader produces 0..4)
-                if (tab_tri[rowbase + j] & 0x88)
-                    return fail(SAT_EINVAL, "entry %d: tableau code 0x%02x at (%d,%d) has a nibble above 7", e, tab_tri[rowbase + j], i, j);
-                float d = dist_tri[rowbase + j];
-                if (std::isfinite(d) && std::fabs(d) >= 1.0e29f)
-                    return fail(SAT_EINVAL, "entry %d: distance %g at (%d,%d) out of range", e, d, i, j);
-            }
-        }
         int64_t end = cell_off[e] + (int64_t)n * (n + 1) / 2;
         if (end > cells_end) cells_end = end;
         if (db_ordinal && (db_ordinal[e] < 0 || db_ordinal[e] > 0xFFFFFFFFll))
             return fail(SAT_EINVAL, "entry %d: db ordinal out of range", e);
+    }
+    auto first_bad_entry = [&](int e0, int e1) -> int {
+        for (int e = e0; e < e1; e++) {
+            const int n = orders[e];
+            uint32_t bad = 0;
+            for (int i = 0; i < n; i++) {
+                const int64_t rowbase = cell_off[e] + (int64_t)i * (i + 1) / 2;
+                const uint8_t *trow = tab_tri + rowbase;
+                const float *drow = dist_tri + rowbase;
+                uint32_t codes = 0, far = 0;
+                for (int j = 0; j < i; j++) {
+                    codes |= trow[j];
+                    const float ad = std::fabs(drow[j]);
+                    far |= (uint32_t)(ad >= 1.0e29f) & (uint32_t)(ad <= 3.4028234e38f);   // finite and out of range
+                }
+                bad |= (codes & 0x88u) | far | (uint32_t)(trow[i] > 3);
+            }
+            if (bad) return e;
+        }
+        return -1;
+    };
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nthreads = (int)(hw ? (hw < 8 ? hw : 8) : 1);
+        if (n_entries < 4096) nthreads = 1;
+        std::vector<int> found((size_t)nthreads, -1);
+        std::vector<std::thread> pool;
+        const int per = (n_entries + nthreads - 1) / nthreads;
+        for (int t = 1; t < nthreads; t++)
+            pool.emplace_back([&, t] { found[(size_t)t] = first_bad_entry(t * per < n_entries ? t * per : n_entries,
+                                                                            (t + 1) * per < n_entries ? (t + 1) * per : n_entries); });
+        found[0] = first_bad_entry(0, per < n_entries ? per : n_entries);
+        for (auto &th : pool) th.join();
+        for (int t = 0; t < nthreads; t++) {
+            const int e = found[(size_t)t];
+            if (e < 0) continue;
+            const int n = orders[e];
+            for (int i = 0; i < n; i++) {
+                const int64_t rowbase = cell_off[e] + (int64_t)i * (i + 1) / 2;
+                uint8_t ty = tab_tri[rowbase + i];
+                if (ty > 3) return fail(SAT_EINVAL, "entry %d: SSE %d has type code %u (0..3 expected)", e, i, ty);
+                for (int j = 0; j < i; j++) {
+                    // the packed pair arithmetic needs nibbles 0..7 (the reader produces 0..4)
+                    if (tab_tri[rowbase + j] & 0x88)
+                        return fail(SAT_EINVAL, "entry %d: tableau code 0x%02x at (%d,%d) has a nibble above 7", e, tab_tri[rowbase + j], i, j);
+                    float d = dist_tri[rowbase + j];
+                    if (std::isfinite(d) && std::fabs(d) >= 1.0e29f)
+                        return fail(SAT_EINVAL, "entry %d: distance %g at (%d,%d) out of range", e, d, i, j);
+                }
+            }
+            return fail(SAT_EINVAL, "entry %d: invalid cell", e);     // not reached: the scan and the re-check agree
+        }
     }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
