@@ -390,6 +390,31 @@ def test_inputs_outside_the_kernel_domain_are_rejected():
             s.set_query(qt, qd, qtypes2)
 
 
+def test_threaded_upload_scan_finds_the_first_bad_entry():
+    """Databases of 4096+ entries are validated by several host threads (branch-free scan, then a
+    cell-by-cell re-check of the earliest flagged entry): the reported entry must be the first bad
+    one in file order whichever thread's range it falls in, and values that only LOOK suspicious to
+    the scan's wider net (the unused diagonal distances) must not be rejected."""
+    with sat.Searcher(0) as s:
+        db = sat.synth.make_db(9000, 6, 12, seed=3)
+        tri = lambda e, i, j: int(db.cell_off[e]) + i * (i + 1) // 2 + j
+        for first, later in ((8123, 8900), (17, 8123), (4500, 4501)):
+            tab = db.tab.copy(); dist = db.dist.copy()
+            tab[tri(later, 3, 1)] = 0x99
+            dist[tri(first, 4, 2)] = -7.0e29
+            with pytest.raises(sat.SatError, match=f"entry {first}: distance"):
+                s.upload(sat.StructSet(db.orders, db.names, db.cell_off, tab, dist))
+        tab = db.tab.copy()
+        tab[tri(7000, 2, 2)] = 7                       # a type code above 3 on the diagonal
+        with pytest.raises(sat.SatError, match="entry 7000: SSE 2 has type code 7"):
+            s.upload(sat.StructSet(db.orders, db.names, db.cell_off, tab, db.dist))
+        dist = db.dist.copy()
+        dist[tri(5000, 3, 3)] = 5.0e30                 # diagonal distances are never read: accepted
+        dist[tri(5001, 2, 1)] = np.inf                 # non-finite: accepted, becomes the sentinel
+        s.upload(sat.StructSet(db.orders, db.names, db.cell_off, db.tab, dist))
+        assert s.n_entries == 9000
+
+
 def test_error_behaviour():
     with sat.Searcher(0) as s:
         with pytest.raises(sat.SatError, match="no database"):
