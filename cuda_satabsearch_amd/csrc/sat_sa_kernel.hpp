@@ -876,10 +876,16 @@ sat_sa_kernel(const SatKernelArgs a)
                     const int rest = total_items - first;
                     if (rest > 0) {
                         if (cmp_wpl > 1 && rest <= tail1_rows) {
-                            const int l = lane_id & 63, rsub = __mul24(l, tail1_recip) >> 16;
+                            // (lane -> (row, word) of a tail shape is worked out here every time: hoisted out
+                            // of the step loop these values would sit in registers the main shape needs)
+                            int l = lane_id & 63;
+                            asm volatile("" : "+v"(l));
+                            const int rsub = __mul24(l, tail1_recip) >> 16;
                             one_round(std::integral_constant<int, 1>{}, first, n1w, rsub, l - __mul24(rsub, n1w), rsub < tail1_rows);
                         } else if (cmp_wpl > 2 && rest <= tail2_rows) {
-                            const int l = lane_id & 63, rsub = __mul24(l, tail2_recip) >> 16;
+                            int l = lane_id & 63;
+                            asm volatile("" : "+v"(l));
+                            const int rsub = __mul24(l, tail2_recip) >> 16;
                             one_round(std::integral_constant<int, 2>{}, first, tail2_lpi, rsub, l - __mul24(rsub, tail2_lpi), rsub < tail2_rows);
                         } else {
                             main_round(first);
