@@ -155,9 +155,12 @@ def main():
     searcher.upload(db, db_ordinal=np.arange(rank * n_local, (rank + 1) * n_local))
     upload_ms = (time.perf_counter() - t_up) * 1e3        # host -> HBM of the packed shard (synchronous copies)
     searcher.set_query(qt, qd, qtypes, 0)
-    scores_dev = searcher.device_scores_tensor()
     # launch on torch's current stream: the RCCL gather and the timing events follow the kernel
     searcher.use_stream(torch.cuda.current_stream().cuda_stream)
+    # the device score buffer is asked for AFTER a search has been queued (satabsearch.h: pointer
+    # lifetime); it then stays where it is until the next upload / query change
+    searcher.search_async(True, False, MAXSTART)
+    scores_dev = searcher.device_scores_tensor()
 
     def gather():
         if args.backend == "nccl":
@@ -197,7 +200,8 @@ def main():
         if rank == 0:
             # the gathered array is the whole database in file order: shard 0 must be rank 0's own scores
             assert gathered.shape[0] == total
-            assert torch.equal(gathered[:n_local].cpu(), scores_dev.cpu()[:n_local])
+            own, _ = searcher.results()                    # rank 0's shard, copied by the library itself
+            assert np.array_equal(gathered[:n_local].cpu().numpy(), own)
 
     if rank == 0:
         scorings = total * args.steps

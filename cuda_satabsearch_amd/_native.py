@@ -104,6 +104,7 @@ def host_lib():
         lib.sat_read_structures_file.restype = C.c_int
         lib.sat_set_save_binary.argtypes = [C.POINTER(StructSetC), C.c_char_p]
         lib.sat_set_load_binary.argtypes = [C.c_char_p, C.POINTER(StructSetC)]
+        lib.sat_set_write_ascii.argtypes = [C.POINTER(StructSetC), C.c_char_p]
         lib.sat_distance_cell.argtypes = [C.c_char_p]
         lib.sat_distance_cell.restype = C.c_float
         lib.sat_norm2.argtypes = [C.c_int, C.c_int, C.c_int]

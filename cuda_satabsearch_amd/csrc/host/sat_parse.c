@@ -137,7 +137,7 @@ static void read_line(FILE *fp, char *buf)
 
 int sat_read_structures(FILE *fp, sat_struct_set *set, const char *what)
 {
-    static char buf[SAT_MAX_LINE_LEN];
+    char buf[SAT_MAX_LINE_LEN];            /* automatic: the readers may run on several threads */
     uint8_t *tri_tab = (uint8_t *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2);
     float *tri_dist = (float *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2 * sizeof(float));
     char name[SAT_LABELSIZE + 1];
@@ -159,6 +159,13 @@ int sat_read_structures(FILE *fp, sat_struct_set *set, const char *what)
             for (int i = 0; i < 2 * order; i++)
                 read_line(fp, buf);
             skipped++;
+            continue;
+        }
+        if (order < 1) {
+            /* no rows follow a record of order 0; a negative order has no meaning (the reference
+             * keeps such a record and then indexes with it: undefined there, dropped here) */
+            fprintf(stderr, "WARNING: excluded %s structure %s: order %d is not positive\n", what, name, order);
+            set->skipped++;
             continue;
         }
         int64_t c = 0;
@@ -278,7 +285,7 @@ float sat_distance_cell(const char *text)
 
 int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, const char *what)
 {
-    static char buf[SAT_MAX_LINE_LEN];
+    char buf[SAT_MAX_LINE_LEN];
     uint8_t *tri_tab = (uint8_t *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2);
     float *tri_dist = (float *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2 * sizeof(float));
     char name[SAT_LABELSIZE + 1];
@@ -301,6 +308,11 @@ int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, c
             for (int i = 0; i < 2 * order; i++)
                 next_line(&c, buf, &dirty);
             skipped++;
+            continue;
+        }
+        if (order < 1) {
+            fprintf(stderr, "WARNING: excluded %s structure %s: order %d is not positive\n", what, name, order);
+            set->skipped++;
             continue;
         }
         int64_t k = 0;
@@ -344,6 +356,56 @@ int sat_read_structures_file(const char *path, sat_struct_set *set, const char *
     int n = sat_read_structures_mem((const char *)map, (size_t)st.st_size, set, what);
     munmap(map, (size_t)st.st_size);
     return n;
+}
+
+/* ------------------------------------------------------------------ ASCII writer */
+
+int sat_set_write_ascii(const sat_struct_set *set, const char *path)
+{
+    /* the database builder's format (scripts/convdb2.py:214-226): "%-8s %4d" header, rows of
+     * two-letter codes + blank, rows of "%6.3f " distances, blank line between records */
+    static const char hi[] = "PROL?", lo[] = "EDST?";
+    static const char *tname[4] = { "e  ", "xa ", "xi ", "xg " };
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    char *line = (char *)malloc((size_t)SAT_MAXDIM * 16 + 64);
+    if (!line) { fclose(f); return -1; }
+    int ok = 1;
+    for (int s = 0; ok && s < set->count; s++) {
+        const int n = set->order[s];
+        const uint8_t *t = set->tab + set->cell_off[s];
+        const float *d = set->dist + set->cell_off[s];
+        ok = fprintf(f, "%-8s %4d\n", sat_set_name(set, s), n) > 0;
+        int64_t c = 0;
+        for (int i = 0; ok && i < n; i++) {
+            char *w = line;
+            for (int j = 0; j <= i; j++, c++) {
+                if (i == j) {
+                    memcpy(w, tname[t[c] & 3], 3);
+                } else {
+                    const int h = t[c] >> 4, l = t[c] & 15;
+                    w[0] = hi[h < 4 ? h : 4];
+                    w[1] = lo[l < 4 ? l : 4];
+                    w[2] = ' ';
+                }
+                w += 3;
+            }
+            *w++ = '\n';
+            ok = fwrite(line, 1, (size_t)(w - line), f) == (size_t)(w - line);
+        }
+        c = 0;
+        for (int i = 0; ok && i < n; i++) {
+            char *w = line;
+            for (int j = 0; j <= i; j++, c++)
+                w += snprintf(w, 16, "%6.3f ", (double)d[c]);
+            *w++ = '\n';
+            ok = fwrite(line, 1, (size_t)(w - line), f) == (size_t)(w - line);
+        }
+        ok = ok && fputc('\n', f) != EOF;
+    }
+    free(line);
+    if (fclose(f) != 0) ok = 0;
+    return ok ? 0 : -1;
 }
 
 /* ------------------------------------------------------------------ binary image */
@@ -390,8 +452,8 @@ int sat_set_load_binary(const char *path, sat_struct_set *set)
         int64_t expect = 0;
         for (size_t s = 0; ok && s < n; s++) {          /* offsets must be the running sum of the triangles */
             int o = tmp.order[s];
-            ok = o <= SAT_MAXDIM && tmp.cell_off[s] == expect && tmp.name[s * (SAT_LABELSIZE + 1) + SAT_LABELSIZE] == '\0';
-            expect += o > 0 ? (int64_t)o * (o + 1) / 2 : 0;
+            ok = o >= 1 && o <= SAT_MAXDIM && tmp.cell_off[s] == expect && tmp.name[s * (SAT_LABELSIZE + 1) + SAT_LABELSIZE] == '\0';
+            expect += (int64_t)o * (o + 1) / 2;
         }
         ok = ok && expect == hdr[1];
         tmp.count = tmp.capacity = (int)n;

@@ -44,7 +44,7 @@ typedef struct sat_struct_set {
     int64_t  *cell_off;   /* [count]  first cell of structure s                       */
     uint8_t  *tab;        /* [cells]  packed code bytes (diagonal = SSE type)         */
     float    *dist;       /* [cells]  distances in Angstrom (diagonal = type as x.000)*/
-    int       skipped;    /* structures dropped because order > SAT_MAXDIM            */
+    int       skipped;    /* structures dropped: order > SAT_MAXDIM or order < 1       */
 } sat_struct_set;
 
 void sat_set_init(sat_struct_set *set);
@@ -85,6 +85,13 @@ int sat_read_structures_file(const char *path, sat_struct_set *set, const char *
  */
 int sat_set_save_binary(const sat_struct_set *set, const char *path);
 int sat_set_load_binary(const char *path, sat_struct_set *set);
+
+/*
+ * Write the set in the ASCII format the readers above parse (and the reference's database
+ * builder scripts/convdb2.py:214-226 emits): "%-8s %4d" header, tableau rows, "%6.3f " distance
+ * rows, a blank line after each record.  Returns 0 / -1.
+ */
+int sat_set_write_ascii(const sat_struct_set *set, const char *path);
 
 /* Expand structure s to dense symmetric pitch x pitch arrays (row-major). */
 void sat_set_expand(const sat_struct_set *set, int s, int pitch,

@@ -7,6 +7,7 @@
 // :1036-1087 and :1128-1270).  No CPU search path exists in this library.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -119,6 +120,7 @@ void free_db(sat_ctx *ctx)
     ctx->ssemaps_cap = 0;
     ctx->desc_dirty = true;
     ctx->n_entries = 0;
+    ctx->searched_nq = 0;
     ctx->h_orders.clear();
 }
 
@@ -275,6 +277,10 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     a.phase = d_phase;
 #endif
 
+    struct Planned {
+        kernel_fn fn; SatKernelArgs args; int count, nqc, threads, n2max, max_entries; size_t lds, slab_words;
+    };
+    std::vector<Planned> plan;
     for (int c = 0; c < 4; c++) {
         const int nqc = ctx->class_begin[c + 1] - ctx->class_begin[c];
         if (nqc == 0) continue;
@@ -306,9 +312,9 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             // work compaction needs sparse maps: with LORDER = F almost every step proposes a real
             // new image, the static loops win and the tables would only cost LDS
             bool compact = lorder != 0;
-            if (const char *ov = getenv("SAT_EXP_COMPACT")) compact = atoi(ov) != 0;
+            if (ctx->tune.compact >= 0) compact = ctx->tune.compact != 0;
             bool qlds = n1p < 32;
-            if (const char *ov = getenv("SAT_EXP_QLDS")) qlds = atoi(ov) != 0 || n1p < 32;
+            if (ctx->tune.qlds >= 0) qlds = ctx->tune.qlds != 0 || n1p < 32;
             size_t lds = 0;
             for (;;) {
                 lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains, lsoln != 0, qlds, compact);
@@ -334,10 +340,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                 lpc_shift = l;
                 if ((int)(kLdsLimit / lds_l) * ((chains << l) / 64) >= 8) break;
             }
-            if (const char *ov = getenv("SAT_EXP_LPC")) {
-                int v = atoi(ov);
-                if (v >= 0 && v <= 2 && (chains << v) <= 1024) lpc_shift = v;
-            }
+            if (ctx->tune.lpc >= 0 && ctx->tune.lpc <= 2 && (chains << ctx->tune.lpc) <= 1024) lpc_shift = ctx->tune.lpc;
             // the per-wave tables grow with the lanes: re-size, backing off if that no longer fits
             for (;; lpc_shift--) {
                 lds = satk::lds_bytes(n1max, n1p, n2max, chains, chains << lpc_shift, lsoln != 0, qlds, compact);
@@ -345,59 +348,94 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             }
             const int threads = chains << lpc_shift;
             // experiment knob: extra (unused) LDS bytes per workgroup, to lower the occupancy
-            if (const char *ov = getenv("SAT_EXP_LDS_PAD")) {
-                const size_t pad = (size_t)atoi(ov);
-                if (lds + pad <= kLdsLimit) lds += pad;
-            }
+            if (ctx->tune.lds_pad && lds + ctx->tune.lds_pad <= kLdsLimit) lds += ctx->tune.lds_pad;
             a.lpc_shift = lpc_shift;
             a.compact = compact ? 1 : 0;
             // option-specialised instantiation when the layout is the default one for these options
-            const bool special = lpc_shift == 0 && compact == (lorder != 0) && !getenv("SAT_EXP_GENERAL");
+            const bool special = lpc_shift == 0 && compact == (lorder != 0) && !ctx->tune.general;
             const int opt = special ? (lorder ? 1 : 0) | (lsoln ? 2 : 0) : -1;
             kernel_fn fn = pick_kernel(n1p, m2w, qlds, opt, ctx->class_wpl[c]);
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            if (ctx->lds_attr_done.insert(reinterpret_cast<const void *>(fn)).second)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
             a.entry_list = ctx->d_lists + (one_launch ? 0 : ctx->bucket_begin[b]);
-            // LSOLN: every workgroup of a launch owns a slab of best maps in global memory; launches
-            // are cut so that the slabs stay under 1 GiB (they are reused launch after launch on the
-            // same stream).  grid.y is limited to 65535: very long query lists are split too.
-            const size_t slab_words = lsoln ? (size_t)((n1max + 3) / 4) * chains : 0;
-            int max_entries = count;
-            if (lsoln) {
-                const size_t budget_words = ((size_t)1 << 30) / 4;
-                size_t per_query_col = slab_words;                 // one workgroup
-                size_t fit = budget_words / per_query_col;         // workgroups per launch
-                if (fit < 1) fit = 1;
-                const int qn_cap = nqc < 65535 ? nqc : 65535;
-                max_entries = (int)(fit / (size_t)qn_cap);
-                if (max_entries < 1) max_entries = 1;
-                if (max_entries > count) max_entries = count;
-            }
-            for (int q0 = 0; q0 < nqc; q0 += 65535) {
-                const int qn = nqc - q0 < 65535 ? nqc - q0 : 65535;
-                for (int e0 = 0; e0 < count; e0 += max_entries) {
-                    const int en = count - e0 < max_entries ? count - e0 : max_entries;
-                    SatKernelArgs part = a;
-                    part.queries = a.queries + q0;
-                    part.entry_list = a.entry_list + e0;
-                    if (lsoln) {
-                        const size_t need = slab_words * (size_t)en * qn;
-                        if (need > ctx->bmap_slabs_cap) {
-                            HIP_TRY(hipStreamSynchronize(stream));
-                            dev_free(ctx->d_bmap_slabs);
-                            HIP_TRY(hipMalloc(&ctx->d_bmap_slabs, need * sizeof(uint32_t)));
-                            ctx->bmap_slabs_cap = need;
-                        }
-                        part.bmap_slabs = ctx->d_bmap_slabs;
-                        part.bmap_slab_words = (uint32_t)slab_words;
-                    }
-                    hipLaunchKernelGGL(fn, dim3(en, qn), dim3(threads), lds, stream, part);
-                    HIP_TRY(hipGetLastError());
+            Planned pl;
+            pl.fn = fn;
+            pl.args = a;
+            pl.count = count;
+            pl.nqc = nqc;
+            pl.threads = threads;
+            pl.lds = lds;
+            pl.n2max = n2max;
+            pl.slab_words = lsoln ? (size_t)((n1max + 3) / 4) * chains : 0;
+            plan.push_back(pl);
+        }
+    }
+
+    // The launches of one search (order buckets x query classes) are independent.  Queued on ONE stream
+    // each would wait for the last workgroups of the one before it (a tail of half-empty CUs per
+    // launch); forked over side streams they run concurrently and the next bucket's workgroups fill
+    // the tail.  Largest entries first: their workgroups run longest.  One launch needs no fork.
+    std::stable_sort(plan.begin(), plan.end(), [](const Planned &x, const Planned &y) { return x.n2max > y.n2max; });
+    const bool fork = plan.size() > 1 && ctx->tune.streams != 0 && ctx->side_stream[0] != nullptr;
+    const int nlanes = fork ? (int)(plan.size() < (size_t)kNumBuckets ? plan.size() : (size_t)kNumBuckets) : 1;
+    if (fork) HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
+    // LSOLN: every workgroup of a launch owns a slab of best maps in global memory; launches are cut so
+    // that the slabs of all concurrent launches stay under 1 GiB together (a lane of launches reuses
+    // its region launch after launch).  grid.y is limited to 65535: very long query lists are split too.
+    const size_t lane_budget_words = ((size_t)1 << 30) / 4 / (size_t)nlanes;
+    if (lsoln) {
+        size_t need_total = 0;
+        for (size_t i = 0; i < plan.size(); i++) {
+            Planned &pl = plan[i];
+            size_t fit = lane_budget_words / pl.slab_words;           // workgroups per launch
+            if (fit < 1) fit = 1;
+            const int qn_cap = pl.nqc < 65535 ? pl.nqc : 65535;
+            pl.max_entries = (int)(fit / (size_t)qn_cap);
+            if (pl.max_entries < 1) pl.max_entries = 1;
+            if (pl.max_entries > pl.count) pl.max_entries = pl.count;
+            const size_t need = pl.slab_words * (size_t)pl.max_entries * (size_t)qn_cap;
+            if (need > need_total) need_total = need;
+        }
+        need_total *= (size_t)nlanes;                                  // one region per lane of launches
+        if (need_total > ctx->bmap_slabs_cap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            dev_free(ctx->d_bmap_slabs);
+            HIP_TRY(hipMalloc(&ctx->d_bmap_slabs, need_total * sizeof(uint32_t)));
+            ctx->bmap_slabs_cap = need_total;
+        }
+    }
+    const size_t lane_region_words = lsoln ? ctx->bmap_slabs_cap / (size_t)nlanes : 0;
+    for (size_t i = 0; i < plan.size(); i++) {
+        const Planned &pl = plan[i];
+        const int lane = fork ? (int)(i % (size_t)nlanes) : 0;
+        hipStream_t s = fork ? ctx->side_stream[lane] : stream;
+        if (fork && i < (size_t)nlanes) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_fork, 0));
+        const int max_entries = lsoln ? pl.max_entries : pl.count;
+        for (int q0 = 0; q0 < pl.nqc; q0 += 65535) {
+            const int qn = pl.nqc - q0 < 65535 ? pl.nqc - q0 : 65535;
+            for (int e0 = 0; e0 < pl.count; e0 += max_entries) {
+                const int en = pl.count - e0 < max_entries ? pl.count - e0 : max_entries;
+                SatKernelArgs part = pl.args;
+                part.queries = pl.args.queries + q0;
+                part.entry_list = pl.args.entry_list + e0;
+                if (lsoln) {
+                    part.bmap_slabs = ctx->d_bmap_slabs + (size_t)lane * lane_region_words;
+                    part.bmap_slab_words = (uint32_t)pl.slab_words;
                 }
+                hipLaunchKernelGGL(pl.fn, dim3(en, qn), dim3(pl.threads), pl.lds, s, part);
+                HIP_TRY(hipGetLastError());
             }
         }
     }
+    if (fork)
+        for (int lane = 0; lane < nlanes; lane++) {
+            HIP_TRY(hipEventRecord(ctx->ev_join[lane], ctx->side_stream[lane]));
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_join[lane], 0));
+        }
+    ctx->searched_nq = ctx->queries.size();
+    ctx->searched_lsoln = lsoln != 0;
 #ifdef SAT_PHASE_TIMING
     {
         unsigned long long h[8];
@@ -453,6 +491,22 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         ctx->stream = ctx->own_stream;
         HIP_TRY(hipEventCreate(&ctx->ev0));
         HIP_TRY(hipEventCreate(&ctx->ev1));
+        // launch-heuristic overrides: read once here, never on the search path
+        auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
+        ctx->tune.compact = env_int("SAT_EXP_COMPACT", -1);
+        ctx->tune.qlds = env_int("SAT_EXP_QLDS", -1);
+        ctx->tune.lpc = env_int("SAT_EXP_LPC", -1);
+        ctx->tune.general = env_int("SAT_EXP_GENERAL", 0);
+        ctx->tune.streams = env_int("SAT_EXP_STREAMS", -1);
+        const int pad = env_int("SAT_EXP_LDS_PAD", 0);
+        ctx->tune.lds_pad = pad > 0 ? (size_t)pad : 0;
+        if (ctx->tune.streams != 0) {
+            for (int b = 0; b < kNumBuckets; b++) {
+                HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream[b], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[b], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        }
         return build_metropolis_table(ctx);
     };
     if (init() != SAT_OK) {
@@ -475,6 +529,11 @@ void sat_ctx_destroy(sat_ctx *ctx)
     dev_free(ctx->d_prow);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int b = 0; b < kNumBuckets; b++) {
+        if (ctx->ev_join[b]) (void)hipEventDestroy(ctx->ev_join[b]);
+        if (ctx->side_stream[b]) (void)hipStreamDestroy(ctx->side_stream[b]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -589,6 +648,7 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
     HIP_TRY(hipMemcpy(ctx->d_tab, tab_tri, (size_t)cells_end, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_dist, dist_tri, (size_t)cells_end * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(ctx->d_scores, 0, (size_t)n_entries * sizeof(int32_t)));
+    ctx->scores_cap = (size_t)n_entries;     // what refresh_descriptors compares with: no re-allocation for one query
     ctx->n_entries = n_entries;
     ctx->h_orders.assign(orders, orders + n_entries);
     return SAT_OK;
@@ -698,6 +758,7 @@ int sat_queries_set(sat_ctx *ctx, int n_queries, const int32_t *n1s, const uint8
     HIP_TRY(hipMemcpy(ctx->d_qblob, blob.data(), blob_bytes, hipMemcpyHostToDevice));
     ctx->queries.swap(infos);
     ctx->desc_dirty = true;
+    ctx->searched_nq = 0;                     // the result buffers no longer belong to the current batch
     return SAT_OK;
 }
 
@@ -756,13 +817,14 @@ int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps)
     if (!scores) return fail(SAT_EINVAL, "scores buffer is null");
     if (lsoln && !ssemaps) return fail(SAT_EINVAL, "lsoln set but ssemaps buffer is null");
     if (ctx->n_entries <= 0) return fail(SAT_ESTATE, "no database uploaded");
-    if (ctx->queries.empty() || !ctx->d_scores) return fail(SAT_ESTATE, "no search has run");
+    if (ctx->queries.empty() || !ctx->d_scores || ctx->searched_nq != ctx->queries.size())
+        return fail(SAT_ESTATE, "no search has run since the last database upload / query change");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t nq = ctx->queries.size(), N = (size_t)ctx->n_entries;
     HIP_TRY(hipMemcpy(scores, ctx->d_scores, nq * N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (lsoln) {
-        if (!ctx->d_ssemaps || !ctx->desc_lsoln) return fail(SAT_ESTATE, "no search with lsoln has run");
+        if (!ctx->d_ssemaps || !ctx->searched_lsoln) return fail(SAT_ESTATE, "the last search ran without lsoln");
         std::vector<int8_t> packed;
         for (size_t qi = 0; qi < nq; qi++) {
             const auto &q = ctx->queries[qi];

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <unordered_set>
 #include <vector>
 
 #include "satabsearch.h"
@@ -44,6 +45,19 @@ struct sat_ctx {
     // Metropolis table
     float *d_ptab = nullptr;
     int32_t *d_prow = nullptr;
+
+    // launch-heuristic overrides (SAT_EXP_* in satabsearch.h), read ONCE when the context is created
+    struct Tuning { int compact = -1, qlds = -1, lpc = -1, general = 0, streams = -1; size_t lds_pad = 0; } tune;
+    // kernel instantiations whose dynamic-LDS limit has been raised on this device
+    std::unordered_set<const void *> lds_attr_done;
+    // side streams: the order buckets of one search run concurrently (each launch has a tail of
+    // half-empty CUs; the next bucket's workgroups fill it), forked from / joined to `stream`
+    hipStream_t side_stream[kNumBuckets] = { nullptr };
+    hipEvent_t ev_fork = nullptr, ev_join[kNumBuckets] = { nullptr };
+
+    // what the result buffers hold: set by a search, cleared by an upload or a new query batch
+    size_t searched_nq = 0;                  // 0 = no search since the last upload / query change
+    bool searched_lsoln = false;
 
     // results: scores [nq][N]; ssemaps: query q's [N][n1_q] block at queries[q].ssemap_off
     int32_t *d_scores = nullptr;

@@ -37,8 +37,8 @@ extern "C" int sat_topk(sat_ctx *ctx, int query, int k, int32_t *entry_index, in
 {
     if (!ctx) return sat_fail(SAT_EINVAL, "null context");
     if (!entry_index || !scores_out || k < 1) return sat_fail(SAT_EINVAL, "bad top-k arguments");
-    if (ctx->n_entries <= 0 || ctx->queries.empty() || !ctx->d_scores)
-        return sat_fail(SAT_ESTATE, "no search has run");
+    if (ctx->n_entries <= 0 || ctx->queries.empty() || !ctx->d_scores || ctx->searched_nq != ctx->queries.size())
+        return sat_fail(SAT_ESTATE, "no search has run since the last database upload / query change");
     if (query < 0 || query >= (int)ctx->queries.size()) return sat_fail(SAT_EINVAL, "query %d out of range", query);
     const int n = ctx->n_entries;
     if (k > n) k = n;

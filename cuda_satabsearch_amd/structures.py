@@ -93,6 +93,12 @@ class StructSet:
         if _native.host_lib().sat_set_save_binary(C.byref(cset), str(path).encode()) != 0:
             raise OSError(f"cannot write {path}")
 
+    def write_ascii(self, path):
+        """Write the set in the reference's ASCII database format (C writer, sat_parse.h)."""
+        cset = self._to_cset()
+        if _native.host_lib().sat_set_write_ascii(C.byref(cset), str(path).encode()) != 0:
+            raise OSError(f"cannot write {path}")
+
     @classmethod
     def load_binary(cls, path):
         host = _native.host_lib()

@@ -15,9 +15,9 @@ throughput is measured on synthetic structures of the named shape:
   scripts/convdb2.py:214-226) and kept below 100 A so the 7-column parse quirk of the
   reader is not triggered.
 
-Everything is deterministic in (seed, index): chunked generation gives the same
-structures as one-shot generation, so every rank of a multi-GPU run can generate its
-own shard.
+Everything is deterministic in (seed, index, orders of the whole database): structures are
+generated in chunks of 1024 at the largest order of their chunk, so every rank of a multi-GPU
+run can generate its own shard and gets the matching slice of the whole database.
 """
 import numpy as np
 
@@ -44,25 +44,41 @@ def _orders(n, lo, hi, seed, sort):
 CHUNK = 1024   # structures per generation chunk: chunk c is a pure function of (seed, c)
 
 
+# 256-entry lookup tables: a uniform byte -> code / type with the measured frequencies (to 1/256)
+def _lut(values, probs):
+    edges = np.round(np.cumsum(probs / probs.sum()) * 256).astype(int)
+    lut = np.empty(256, np.uint8)
+    lo = 0
+    for v, hi in zip(values, edges):
+        lut[lo:hi] = v
+        lo = hi
+    lut[lo:] = values[-1]
+    return lut
+
+
+_CODE_LUT = _lut(_CODES, _CODE_P)
+_TYPE_LUT = _lut(_TYPES, _TYPE_P)
+
+
 def _chunk(c, nmax, seed):
     """Structures c*CHUNK .. c*CHUNK+CHUNK-1 at order nmax: (tabs, dists) [CHUNK, nmax, nmax]."""
     n = CHUNK
-    rng = np.random.Generator(np.random.Philox(key=seed, counter=[0, 0, c, 0]))
-    types = rng.choice(_TYPES, size=(n, nmax), p=_TYPE_P / _TYPE_P.sum())
-    codes = rng.choice(_CODES, size=(n, nmax, nmax), p=_CODE_P / _CODE_P.sum())
+    rng = np.random.Generator(np.random.Philox(key=seed, counter=[0, 0, c, nmax]))
+    types = _TYPE_LUT[rng.integers(0, 256, size=(n, nmax), dtype=np.uint8)]
+    codes = _CODE_LUT[rng.integers(0, 256, size=(n, nmax, nmax), dtype=np.uint8)]
     step_len = np.clip(rng.normal(10.0, 3.0, size=(n, nmax)), 3.8, 16.0)
     direction = rng.normal(size=(n, nmax, 3))
     direction /= np.linalg.norm(direction, axis=2, keepdims=True)
-    pos = np.cumsum(direction * step_len[:, :, None] * 0.75, axis=1).astype(np.float32)
-    diff = pos[:, :, None, :] - pos[:, None, :, :]
-    d = np.sqrt((diff * diff).sum(axis=3, dtype=np.float64))
+    pos = np.cumsum(direction * step_len[:, :, None] * 0.75, axis=1)
+    # pairwise distances through the Gram matrix (float64), rounded to the 3 decimals of the ASCII format
+    sq = (pos * pos).sum(axis=2)
+    d2 = sq[:, :, None] + sq[:, None, :] - 2.0 * np.matmul(pos, pos.transpose(0, 2, 1))
+    d = np.sqrt(np.maximum(d2, 0.0))
     d = np.minimum(np.round(d, 3), 99.999).astype(np.float32)
-    tabs = np.empty((n, nmax, nmax), np.uint8)
-    dists = np.empty((n, nmax, nmax), np.float32)
     ii, jj = np.tril_indices(nmax)
-    tabs[:, ii, jj] = codes[:, ii, jj]
+    tabs = codes
     tabs[:, jj, ii] = codes[:, ii, jj]
-    dists[:, ii, jj] = d[:, ii, jj]
+    dists = d
     dists[:, jj, ii] = d[:, ii, jj]
     idx = np.arange(nmax)
     tabs[:, idx, idx] = types
@@ -70,21 +86,40 @@ def _chunk(c, nmax, seed):
     return tabs, dists
 
 
-def make_db(n, order_lo=32, order_hi=None, seed=DB_SEED, sort=True, first_index=0, total=None):
+def orders_c5(total, seed=DB_SEED, sort=True):
+    """Orders of the large-structure workload C5 of SURVEY.md section 8d: uniform on [8, 96], and
+    1 % of the entries uniform on [97, 111] (the reference's second, "large" pass)."""
+    rng = np.random.Generator(np.random.Philox(key=seed ^ 0xC5C5))
+    o = rng.integers(8, 97, size=total).astype(np.int32)
+    big = rng.random(total) < 0.01
+    o[big] = rng.integers(97, 112, size=int(big.sum())).astype(np.int32)
+    return np.sort(o) if sort else o
+
+
+def make_db(n, order_lo=32, order_hi=None, seed=DB_SEED, sort=True, first_index=0, total=None, orders=None,
+            name_format="s%07d"):
     """Synthetic database of n structures: entries first_index .. first_index+n-1 of a
     database of `total` structures, so every rank can generate its own shard.  A
-    structure of order m is the leading m x m block of its order-`order_hi` sample."""
+    structure of order m is the leading m x m block of its chunk's sample.
+    `orders` (length `total`) overrides the uniform draw of the orders."""
     order_hi = order_lo if order_hi is None else order_hi
     total = n + first_index if total is None else total
-    all_orders = _orders(total, order_lo, order_hi, seed, sort)
+    if orders is not None:
+        all_orders = np.ascontiguousarray(orders, dtype=np.int32)
+        assert all_orders.shape[0] == total
+        order_lo, order_hi = int(all_orders.min()), int(all_orders.max())
+    else:
+        all_orders = _orders(total, order_lo, order_hi, seed, sort)
     orders = all_orders[first_index:first_index + n]
     ncell = orders.astype(np.int64) * (orders + 1) // 2
     cell_off = np.concatenate([[0], np.cumsum(ncell)[:-1]]).astype(np.int64)
     tab = np.empty(int(ncell.sum()), np.uint8)
     dist = np.empty(int(ncell.sum()), np.float32)
-    nmax = int(order_hi)
     tril = {}
     for c in range(first_index // CHUNK, (first_index + n - 1) // CHUNK + 1):
+        # a chunk is generated at the largest order it holds IN THE WHOLE DATABASE, so that a shard
+        # generated on its own holds the same structures as the matching slice of the whole
+        nmax = int(all_orders[c * CHUNK:(c + 1) * CHUNK].max())
         tabs, dists = _chunk(c, nmax, seed)
         k0 = max(first_index, c * CHUNK)
         k1 = min(first_index + n, (c + 1) * CHUNK)
@@ -95,13 +130,18 @@ def make_db(n, order_lo=32, order_hi=None, seed=DB_SEED, sort=True, first_index=
             tab[o:o + (k1 - k0) * ii.size] = tabs[sl][:, ii, jj].reshape(-1)
             dist[o:o + (k1 - k0) * ii.size] = dists[sl][:, ii, jj].reshape(-1)
             continue
-        for k in range(k0, k1):
-            m = int(orders[k - first_index])
+        # entries of one order at a time: one fancy-index gather per (chunk, order)
+        local = orders[k0 - first_index:k1 - first_index]
+        for m in np.unique(local):
+            m = int(m)
             ii, jj = tril.setdefault(m, np.tril_indices(m))
-            o = int(cell_off[k - first_index])
-            tab[o:o + ii.size] = tabs[k - c * CHUNK][ii, jj]
-            dist[o:o + ii.size] = dists[k - c * CHUNK][ii, jj]
-    names = ["s%07d" % (first_index + k) for k in range(n)]
+            ks = np.nonzero(local == m)[0]
+            src_t = tabs[ks + (k0 - c * CHUNK)][:, ii, jj]
+            src_d = dists[ks + (k0 - c * CHUNK)][:, ii, jj]
+            dst = (cell_off[ks + (k0 - first_index)][:, None] + np.arange(ii.size, dtype=np.int64)[None, :]).reshape(-1)
+            tab[dst] = src_t.reshape(-1)
+            dist[dst] = src_d.reshape(-1)
+    names = [name_format % (first_index + k) for k in range(n)]
     return StructSet(orders, names, cell_off, tab, dist)
 
 
@@ -134,7 +174,8 @@ def planted_query(db: StructSet, s, keep=0.75, jitter=1.0, seed=QUERY_SEED):
 
 def write_ascii(db: StructSet, path):
     """Write the reference's ASCII format (scripts/convdb2.py:214-226): header
-    '%-8s %4d', rows of 2-letter codes + blank, rows of '%6.3f ', blank line between."""
+    '%-8s %4d', rows of 2-letter codes + blank, rows of '%6.3f ', blank line between.
+    (Python loop, kept as the independent check of the C writer StructSet.write_ascii.)"""
     hi = "PROL?"
     lo = "EDST?"
     tname = {0: "e  ", 1: "xa ", 2: "xi ", 3: "xg "}

@@ -13,10 +13,13 @@
  * Errors: every int-returning call yields 0 on success and a negative SAT_E*
  * code otherwise; sat_last_error() has the text.  Nothing in the library calls
  * exit() or abort().  Environment (tuning / test overrides of launch heuristics, results do
- * not depend on them): SAT_EXP_LPC = 0|1|2 (log2 lanes per chain), SAT_EXP_COMPACT = 0|1
+ * not depend on them; read ONCE by sat_ctx_create, never on the search path):
+ * SAT_EXP_LPC = 0|1|2 (log2 lanes per chain), SAT_EXP_COMPACT = 0|1
  * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS),
  * SAT_EXP_LDS_PAD = bytes (unused LDS added per workgroup: occupancy experiments),
- * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones).
+ * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones),
+ * SAT_EXP_STREAMS = 0 (queue the order buckets of a search one after the other instead of
+ * concurrently on side streams).
  * There is no CPU fallback: without a usable HIP device sat_ctx_create() fails with
  * SAT_ENODEVICE.
  */
@@ -160,6 +163,10 @@ int sat_use_own_stream(sat_ctx *ctx);
  *   sat_device_scores()   int32 [n_queries][n_entries]
  *   sat_device_ssemaps()  int8, query q's [n_entries][n1_q] block after those of queries
  *                         0..q-1; -1 = unmatched; valid after a search with lsoln != 0
+ * Pointer lifetime: ask for the pointers AFTER the search has been queued; they stay valid
+ * (and keep that search's results) until the next database upload, the next query / query
+ * batch change or a search with more queries or lsoln newly set - any of these may
+ * re-allocate the buffers.
  * sat_query_order() is the order of query 0.
  */
 int sat_search_async(sat_ctx *ctx, int lorder, int lsoln, int maxstart);
@@ -172,7 +179,8 @@ int sat_sync(sat_ctx *ctx);
 
 /*
  * Wait for the queued search and copy its results to the host, same buffers and
- * layout as sat_search (ssemaps may be NULL when lsoln == 0).  With sat_search_async
+ * layout as sat_search (ssemaps may be NULL when lsoln == 0).  SAT_ESTATE when no search
+ * has run since the last upload / query change, or lsoln is asked of a search without it.  With sat_search_async
  * this lets one host thread keep several devices busy (one context per GPU, the
  * database sharded contiguously): launch on all, then collect from each - the
  * multi-GPU mode the reference left as a TODO (H.cu:790).

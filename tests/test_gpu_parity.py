@@ -120,22 +120,23 @@ def test_large_everything_lds_spill_regime(searcher):
                                  {"SAT_EXP_LPC": "1", "SAT_EXP_COMPACT": "1"}, {"SAT_EXP_LPC": "2", "SAT_EXP_COMPACT": "1"},
                                  {"SAT_EXP_LPC": "2", "SAT_EXP_COMPACT": "0"}, {"SAT_EXP_QLDS": "1"}],
                          ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
-def test_forced_execution_modes(searcher, monkeypatch, env):
+def test_forced_execution_modes(monkeypatch, env):
     """The launch heuristics (lanes per chain, work compaction, query cells in LDS) only change
-    how the work is laid out; forced through the library's tuning overrides, every layout must
-    give the oracle's bits, for both LORDER modes and with solution maps."""
+    how the work is laid out; forced through the library's tuning overrides (read when a context is
+    created), every layout must give the oracle's bits, for both LORDER modes and with solution maps."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     db = sat.synth.make_db(150, 6, 40, seed=21)
-    searcher.upload(db)
-    for src, keep in ((140, 0.8), (20, 1.0)):
-        q = sat.synth.planted_query(db, src, keep=keep)
-        check(searcher, db, q, True, True, 128)
-        check(searcher, db, q, False, True, 100)
+    with sat.Searcher(0) as forced:
+        forced.upload(db)
+        for src, keep in ((140, 0.8), (20, 1.0)):
+            q = sat.synth.planted_query(db, src, keep=keep)
+            check(forced, db, q, True, True, 128)
+            check(forced, db, q, False, True, 100)
 
 
 @pytest.mark.parametrize("general", [False, True], ids=["specialised", "general"])
-def test_round_shapes_of_every_query_order_class(searcher, wide_db, monkeypatch, general):
+def test_round_shapes_of_every_query_order_class(wide_db, monkeypatch, general):
     """The compacted rounds serve a listed row with ceil(n1w/4) lanes x up to 4 map words, pad the
     maps to whole words per lane and send a step's last rows to 1- and 2-word shapes.  One query
     order from every (lanes per row, words per lane, padding) class, LSOLN off so that the
@@ -143,15 +144,16 @@ def test_round_shapes_of_every_query_order_class(searcher, wide_db, monkeypatch,
     (SAT_EXP_GENERAL), which picks the shape at run time."""
     if general:
         monkeypatch.setenv("SAT_EXP_GENERAL", "1")
-    searcher.upload(wide_db)
-    entries = np.arange(0, len(wide_db), 4)
-    for n1 in (3, 4, 8, 9, 12, 13, 19, 21, 24, 25, 28, 36, 37, 40, 45, 48, 52, 61, 68, 77, 84, 100, 109):
-        rng = np.random.default_rng(1000 + n1)
-        src = int(rng.choice(np.nonzero(wide_db.orders >= n1)[0]))
-        t, d = wide_db.dense(src)
-        sel = np.sort(rng.choice(int(wide_db.orders[src]), size=n1, replace=False))
-        q = (t[np.ix_(sel, sel)].copy(), d[np.ix_(sel, sel)].copy(), np.diagonal(t)[sel].copy())
-        check(searcher, wide_db, q, True, False, 64, entries=entries)
+    with sat.Searcher(0) as searcher:              # the override is read when the context is created
+        searcher.upload(wide_db)
+        entries = np.arange(0, len(wide_db), 4)
+        for n1 in (3, 4, 8, 9, 12, 13, 19, 21, 24, 25, 28, 36, 37, 40, 45, 48, 52, 61, 68, 77, 84, 100, 109):
+            rng = np.random.default_rng(1000 + n1)
+            src = int(rng.choice(np.nonzero(wide_db.orders >= n1)[0]))
+            t, d = wide_db.dense(src)
+            sel = np.sort(rng.choice(int(wide_db.orders[src]), size=n1, replace=False))
+            q = (t[np.ix_(sel, sel)].copy(), d[np.ix_(sel, sel)].copy(), np.diagonal(t)[sel].copy())
+            check(searcher, wide_db, q, True, False, 64, entries=entries)
 
 
 def test_batch_of_mixed_round_shapes(searcher, wide_db):
@@ -434,6 +436,52 @@ def test_error_behaviour():
             s.search(maxstart=0)
     with pytest.raises(sat.SatError, match="out of range"):
         sat.Searcher(4096)
+
+
+def test_results_belong_to_the_last_search():
+    """The result buffers are only handed out for the search they were filled by: after a new query
+    batch or a new upload, sat_results / sat_topk refuse until a search has run (the buffers may be
+    too small for the new batch), and solution maps are only served after a search with lsoln."""
+    db = sat.synth.make_db(40, 6, 12, seed=9)
+    q = sat.synth.make_query(8)
+    with sat.Searcher(0) as s:
+        s.upload(db)
+        s.set_query(*q, 0)
+        with pytest.raises(sat.SatError, match="no search has run"):
+            s.results()
+        s.search_async(True, False, 64)
+        one, _ = s.results()
+        with pytest.raises(sat.SatError, match="without lsoln"):
+            s.results(lsoln=True)
+        s.set_queries([q, q, q], 0)                    # three times the rows: the old buffer is too small
+        with pytest.raises(sat.SatError, match="no search has run"):
+            s.results()
+        with pytest.raises(sat.SatError, match="no search has run"):
+            s.topk(3)
+        s.search_async(True, True, 64)
+        three, maps = s.results(lsoln=True)
+        assert three.shape == (3, 40) and np.array_equal(three[0], one)
+        s.upload(db)
+        with pytest.raises(sat.SatError, match="no search has run"):
+            s.results()
+
+
+def test_device_score_buffer_is_the_one_the_search_fills():
+    """sat_device_scores() after a queued search aliases that search's results (what bench.py hands
+    to the RCCL gather), also right after an upload, when the first search must not re-allocate."""
+    import torch
+    db = sat.synth.make_db(3000, 8, 24, seed=4)
+    q = sat.synth.make_query(16)
+    with sat.Searcher(0) as s:
+        for _ in range(2):
+            s.upload(db)
+            s.set_query(*q, 0)
+            before = s.device_scores_ptr()
+            s.search_async(True, False, 64)
+            dev = s.device_scores_tensor()
+            assert s.device_scores_ptr() == before        # one query: the buffer allocated by the upload is used
+            host, _ = s.results()
+            assert np.array_equal(dev.cpu().numpy(), host)
 
 
 # ---------------------------------------------------------------- reference -c stream (T3)
