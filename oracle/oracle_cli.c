@@ -8,7 +8,10 @@
  * :1276-1309, per-query body tabsearch_host_thread :308-459.
  *
  * Extra switches (not in the reference): -p selects the counter-based Philox
- * streams the GPU kernel uses (sa_oracle.h), -s SEED sets their seed, -m N moves
+ * streams the GPU kernel uses (sa_oracle.h), -s SEED sets their seed, -S SEED
+ * seeds the sequential drand48 stream (the reference hard-codes srand48(1234),
+ * :871; other seeds measure its seed-to-seed spread,
+ * tests/golden/make_seed_spread.py), -m N moves
  * the small/large class boundary (96 today, 32 in the 2013 snapshot whose
  * recorded output is one of the golden files).
  *
@@ -81,22 +84,24 @@ int main(int argc, char *argv[])
     int gpu_row_format = 0;   /* -G: large-class rows as the reference GPU path prints them (cudaSaTabsearch.cu:1261) */
     int querydbmode = 0, maxstart = 128, philox = 0, small_limit = SAT_MAXDIM_SMALL;
     unsigned long long seed = 1234;
+    long drand_seed = 1234;
     int ltype = 0, lorder = 0, lsoln = 0;
     char cltype, clorder, clsoln;
     int c;
 
-    while ((c = getopt(argc, argv, "cq:r:ps:m:tG")) != -1) {
+    while ((c = getopt(argc, argv, "cq:r:ps:S:m:tG")) != -1) {
         switch (c) {
         case 'c': break; /* always host */
         case 'q': querydbmode = 1; strncpy(dbfile, optarg, sizeof(dbfile) - 1); break;
         case 'r': maxstart = atoi(optarg); break;
         case 'p': philox = 1; break;
         case 's': seed = strtoull(optarg, NULL, 0); break;
+        case 'S': drand_seed = strtol(optarg, NULL, 0); break;
         case 't': sa_oracle_trace = 1; break;
         case 'G': gpu_row_format = 1; break;
         case 'm': small_limit = atoi(optarg); break; /* 2013 snapshot: MAXDIM_GPU = 32 */
         default:
-            fprintf(stderr, "Usage: %s [-c] [-q dbfile] [-r restarts] [-p] [-s seed] [-m small_class_limit]\n", argv[0]);
+            fprintf(stderr, "Usage: %s [-c] [-q dbfile] [-r restarts] [-p] [-s seed] [-S drand48_seed] [-m small_class_limit]\n", argv[0]);
             exit(1);
         }
     }
@@ -193,7 +198,7 @@ int main(int argc, char *argv[])
     sa_oracle_rng rng;
     memset(&rng, 0, sizeof(rng));
     rng.mode = philox ? SA_RNG_PHILOX : SA_RNG_DRAND48;
-    rng.lcg = sa_oracle_srand48(1234);
+    rng.lcg = sa_oracle_srand48(drand_seed);
     rng.seed = seed;
 
     uint8_t *qtab = (uint8_t *)calloc(SA_MAXDIM * SA_MAXDIM, 1);
