@@ -14,7 +14,7 @@ lines = []
 kern_ns = None
 if stats:
     for r in csv.DictReader(open(stats[0])):
-        if "sat_sa_kernel" in r["Name"]:
+        if "sat_sa_" in r["Name"]:
             kern_ns = float(r["AverageNs"])
             lines.append(f"kernel {r['Name']}: calls {r['Calls']} avg {kern_ns/1e6:.3f} ms min {float(r['MinNs'])/1e6:.3f} max {float(r['MaxNs'])/1e6:.3f}")
 vals = {}
@@ -22,7 +22,7 @@ for p in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.c
     agg = collections.defaultdict(list)
     meta = None
     for r in csv.DictReader(open(p)):
-        if "sat_sa_kernel" in r["Kernel_Name"]:
+        if "sat_sa_" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = r
     for k, v in agg.items():
