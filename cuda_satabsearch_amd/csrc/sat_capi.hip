@@ -19,7 +19,6 @@
 
 #include "satabsearch.h"
 #include "sat_sa_kernel.hpp"
-#include "sat_sa_list_kernel.hpp"
 #include "sat_ctx.hpp"
 
 namespace {
@@ -182,12 +181,6 @@ kernel_fn pick_kernel(int n1p, int m2w, bool qlds, int opt, int wpl)
     }
 }
 
-kernel_fn pick_list_kernel(int n1p, bool lsoln)
-{
-    if (n1p == 16) return lsoln ? sat_sa_list_kernel<16, true> : sat_sa_list_kernel<16, false>;
-    return lsoln ? sat_sa_list_kernel<32, true> : sat_sa_list_kernel<32, false>;
-}
-
 const int kClassN1P[4] = { 16, 32, 64, 112 };
 
 // (re)build the device query descriptors: pointers into the query blob and into the result
@@ -237,7 +230,6 @@ int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
             d.seed_q = ctx->seed + ((uint64_t)q.ordinal << 32);
             d.scores = ctx->d_scores + qi * (size_t)ctx->n_entries;
             d.ssemaps = lsoln ? ctx->d_ssemaps + q.ssemap_off : nullptr;
-            d.qcell = q.cell_off ? reinterpret_cast<const uint2 *>(ctx->d_qblob + q.cell_off) : nullptr;
             desc.push_back(d);
             if (q.n1 > ctx->class_n1max[c]) ctx->class_n1max[c] = q.n1;
             int lpi, wpl;
@@ -311,35 +303,6 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             }
             if (count == 0) continue;
             const int m2w = n2max <= 32 ? 1 : (n2max <= 64 ? 2 : 4);
-
-            // Order-preserving searches of small queries over small entries keep their maps as lists
-            // of matched pairs (sat_sa_list_kernel.hpp): a database scan is sparse, and scoring only
-            // the matched pairs is ~3x less pair arithmetic.  Any forced layout runs the dense kernel.
-            const bool use_list = lorder != 0 && n1p <= 32 && n2max <= 32 && ctx->tune.list != 0 && ctx->tune.lpc < 0 &&
-                                  ctx->tune.compact < 0 && ctx->tune.qlds < 0 && !ctx->tune.general;
-            if (use_list) {
-                int lchains = (maxstart + 63) / 64 * 64;
-                if (lchains > 256) lchains = 256;
-                Planned pl;
-                pl.fn = pick_list_kernel(n1p, lsoln != 0);
-                size_t llds = satk::list_lds_layout(n1max, n1p, n2max, lchains).total;
-                if (ctx->tune.lds_pad && llds + ctx->tune.lds_pad <= kLdsLimit) llds += ctx->tune.lds_pad;
-                if (ctx->lds_attr_done.insert(reinterpret_cast<const void *>(pl.fn)).second)
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pl.fn),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-                a.lpc_shift = 0;
-                a.compact = 1;
-                a.entry_list = ctx->d_lists + (one_launch ? 0 : ctx->bucket_begin[b]);
-                pl.args = a;
-                pl.count = count;
-                pl.nqc = nqc;
-                pl.threads = lchains;
-                pl.lds = llds;
-                pl.n2max = n2max;
-                pl.slab_words = lsoln ? (size_t)(2 * ((n1max + 3) / 4) + 1) * lchains : 0;
-                plan.push_back(pl);
-                continue;
-            }
 
             // chains: one per restart up to 256; shrink until the workgroup fits the LDS.
             // query cells: through L1/L2 for 32-SSE-class queries and up (frees 8+ KB of LDS per
@@ -535,7 +498,6 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         ctx->tune.lpc = env_int("SAT_EXP_LPC", -1);
         ctx->tune.general = env_int("SAT_EXP_GENERAL", 0);
         ctx->tune.streams = env_int("SAT_EXP_STREAMS", -1);
-        ctx->tune.list = env_int("SAT_EXP_LIST", -1);
         const int pad = env_int("SAT_EXP_LDS_PAD", 0);
         ctx->tune.lds_pad = pad > 0 ? (size_t)pad : 0;
         if (ctx->tune.streams != 0) {
@@ -744,12 +706,6 @@ int sat_queries_set(sat_ctx *ctx, int n_queries, const int32_t *n1s, const uint8
         q.ssemap_off = 0;
         const size_t groups = (size_t)q.n1p / 4 * q.n1p;
         blob_bytes += (groups * 20 + (size_t)q.n1p + 15) & ~(size_t)15;
-        // cell matrix of the list kernel (sat_sa_list_kernel.hpp): [n1p][n1p] x {distance, code byte}
-        q.cell_off = 0;
-        if (q.n1p <= 32) {
-            q.cell_off = blob_bytes;
-            blob_bytes += (size_t)q.n1p * q.n1p * 8;
-        }
     }
     // grouped, transposed query: group kw, column i holds dmat1[i][4kw..4kw+3] and the four code
     // bytes tab1[i][4kw..4kw+3]; diagonal, padding and non-finite distances get the sentinel
@@ -791,14 +747,6 @@ int sat_queries_set(sat_ctx *ctx, int n_queries, const int32_t *n1s, const uint8
                 }
                 qdist[(size_t)kw * n1p + i] = float4{ d[0], d[1], d[2], d[3] };
                 qcode[(size_t)kw * n1p + i] = codes;
-                if (q.cell_off) {
-                    uint32_t *cells = reinterpret_cast<uint32_t *>(blob.data() + q.cell_off);
-                    for (int sidx = 0; sidx < 4; sidx++) {
-                        const size_t c = ((size_t)i * n1p + 4 * kw + sidx) * 2;
-                        memcpy(&cells[c], &d[sidx], 4);
-                        cells[c + 1] = (codes >> (8 * sidx)) & 0xFFu;
-                    }
-                }
             }
     }
     HIP_TRY(hipSetDevice(ctx->device));

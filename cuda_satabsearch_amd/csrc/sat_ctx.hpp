@@ -32,7 +32,7 @@ struct sat_ctx {
     std::vector<int32_t> h_orders;
 
     // queries (a batch; one query is a batch of 1), input order
-    struct QueryInfo { int n1, n1p; uint32_t ordinal; size_t blob_off; size_t cell_off; size_t ssemap_off; };   // cell_off: 0 = no cell matrix
+    struct QueryInfo { int n1, n1p; uint32_t ordinal; size_t blob_off; size_t ssemap_off; };
     std::vector<QueryInfo> queries;
     uint8_t *d_qblob = nullptr;             // per query: qdist | qcode | qtypes
     SatQuery *d_qdesc = nullptr;            // descriptors grouped by size class
@@ -47,7 +47,7 @@ struct sat_ctx {
     int32_t *d_prow = nullptr;
 
     // launch-heuristic overrides (SAT_EXP_* in satabsearch.h), read ONCE when the context is created
-    struct Tuning { int compact = -1, qlds = -1, lpc = -1, general = 0, streams = -1, list = -1; size_t lds_pad = 0; } tune;
+    struct Tuning { int compact = -1, qlds = -1, lpc = -1, general = 0, streams = -1; size_t lds_pad = 0; } tune;
     // kernel instantiations whose dynamic-LDS limit has been raised on this device
     std::unordered_set<const void *> lds_attr_done;
     // side streams: the order buckets of one search run concurrently (each launch has a tail of

@@ -103,7 +103,6 @@ struct SatQuery {
     uint64_t        seed_q;       // seed + (query ordinal << 32)
     int32_t        *scores;       // [N] this query's score row
     int8_t         *ssemaps;      // [N][n1] this query's maps, -1 = unmatched
-    const uint2    *qcell;        // [N1P][N1P] cells {distance, code byte} (queries of up to 32 SSEs; list kernel)
 };
 
 struct SatKernelArgs {

@@ -19,8 +19,7 @@
  * SAT_EXP_LDS_PAD = bytes (unused LDS added per workgroup: occupancy experiments),
  * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones),
  * SAT_EXP_STREAMS = 0 (queue the order buckets of a search one after the other instead of
- * concurrently on side streams), SAT_EXP_LIST = 0 (order-preserving searches of queries and
- * entries of up to 32 SSEs run the dense kernel instead of the matched-pair-list kernel).
+ * concurrently on side streams).
  * There is no CPU fallback: without a usable HIP device sat_ctx_create() fails with
  * SAT_ENODEVICE.
  */
