@@ -70,9 +70,10 @@
 // query SSEs, tmask[t] = db SSEs of type t.
 //
 // Random numbers: Philox4x32-10 with rocRAND's counter layout (rocrand_init(seed, subsequence,
-// offset) + rocrand4), written out in philox_block; one 4x32-bit block per SA step, addressed
-// by (seed, query, db ordinal, restart, step) - see oracle/sa_oracle.h for the slot layout,
-// which the CPU oracle restates bit for bit.
+// offset) + rocrand4), written out in philox_block; one 4x32-bit block per TWO SA steps, addressed
+// by (seed, query, db ordinal, restart, step pair): a step takes two words - one split into two
+// 16-bit draws (which query SSE moves, which candidate is taken), one whole for the Metropolis
+// test - see oracle/sa_oracle.h for the slot layout, which the CPU oracle restates bit for bit.
 //
 // Metropolis test: the reference evaluates expf((float)delta / temp) > u with glibc
 // expf on the host path (K.cu:1166).  temp takes 100 values and delta is a small
@@ -270,8 +271,11 @@ __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, co
     const uint32_t x = __builtin_amdgcn_perm(d1.y, d0.y, 0x0C0C0400u) ^
                        __builtin_amdgcn_perm(d3.y, d2.y, 0x04000C0Cu) ^ qc;
     const uint32_t z = (x + 0x77777777u) & 0x88888888u;             // bit 3: low nibbles differ, bit 7: high
-    uint32_t sel = ((z >> 3) | (z >> 6)) & 0x03030303u;
-    sel |= ((far >> 5) & 0x04040404u) | force;
+    // ((z >> 3) | (z >> 6)) & 0x03030303 and the merge of the distance bits as two v_bitop3_b32 (full
+    // rate; the and-or / or3 forms the compiler picks for the plain expression issue at half rate)
+    uint32_t sel = __builtin_amdgcn_bitop3_b32(z >> 3, z >> 6, 0x03030303u, 0xA8);        // (a | b) & c
+    sel = __builtin_amdgcn_bitop3_b32(far >> 5, 0x04040404u, sel, 0xEA);                   // (a & b) | c
+    sel |= force;
     const uint32_t terms = __builtin_amdgcn_perm(0u, 0xFE010102u, sel);   // {2, 1, 1, -2 | 0, 0, 0, 0}
     return __builtin_amdgcn_sdot4((int)terms, 0x01010101, acc, false);
 }
@@ -324,6 +328,17 @@ __device__ __forceinline__ float to_uniform(uint32_t v)
 __device__ __forceinline__ int scaled_index(float w, double n)
 {
     return (int)(__builtin_fma((double)w, 2.3283064365386963e-10, -SAT_K_EPS) * n);
+}
+
+// The same index from a 16-bit draw v: u = (v + 1) * 2^-16 in (0, 1] (exact in float), index =
+// (int)((u - EPS) * n) evaluated in double as above.  For n <= 111 that equals the integer
+// ((v + 1) * n - 1) >> 16: when (v + 1) * n is a multiple of 2^16 the EPS term drops the index by
+// one, otherwise the fractional part is at least 2^-16 > EPS * n and nothing changes
+// (tests/test_oracle_units.py checks all 65536 x 111 cases against the double expression).
+// nm1 = max(n - 1, 0); n = 0 gives 0.
+__device__ __forceinline__ int scaled_index16(uint32_t v16, int n, int nm1)
+{
+    return (int)(__umul24(v16, (uint32_t)n) + (uint32_t)nm1) >> 16;
 }
 
 // Work compaction (SA step): a listed row is served by `lpi` lanes, each taking `wpl` <= 4 map
@@ -696,19 +711,29 @@ sat_sa_kernel(const SatKernelArgs a)
 
         // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
         SAT_PHASE(6);                     // thinit + full score
+        uint4 blk = uint4{ 0u, 0u, 0u, 0u };
         for (int iter = 0; iter < SAT_K_MAXITER; iter++) {
             // this step's row of the Metropolis table.  The directory is read-only for the kernel's
             // lifetime: through the constant address space these are scalar loads (a plain global
             // pointer gets a vector load, whose latency would sit in front of the table load), asked
             // for here so that they are back long before the test at the end of the step
             const int rowoff = prowC[2 * iter], rowmax = prowC[2 * iter + 1];
-            const uint4 r = philox_block(Q.seed_q, subseq, (uint32_t)(SAT_K_STEP_BLOCK0 + iter));
+            // one Philox block per two steps: the even step draws it and uses words 0, 1, the odd step
+            // uses words 2, 3 (moved down).  Word a = two 16-bit draws (moved SSE: high half, candidate:
+            // low half), word b = the Metropolis draw.
+            if ((iter & 1) == 0) {
+                blk = philox_block(Q.seed_q, subseq, (uint32_t)(SAT_K_STEP_BLOCK0 + (iter >> 1)));
+            } else {
+                blk.x = blk.z;
+                blk.y = blk.w;
+            }
+            const uint32_t word_a = blk.x, word_b = blk.y;
 #ifdef SAT_EXP_PERTURB
             satk::perturb(pert);
 #endif
 
             // which query SSE moves (K.cu:1037-1042)
-            const int ssei = scaled_index(draw32(r.x), n1d);
+            const int ssei = scaled_index16(word_a >> 16, n1, n1 - 1);
 
             // candidate db SSEs: free, same type, inside the order window (K.cu:1053-1086)
             int oldj;
@@ -771,7 +796,7 @@ sat_sa_kernel(const SatKernelArgs a)
             // (K.cu:701-702); several: the draw picks the (u - EPS) * cnt -th (K.cu:705-711).
             // Branch-free: in a 64-lane wave every case occurs anyway.
             const int cnt = bits_count<M2W>(cand);
-            const int pick = cnt > 1 ? scaled_index(draw32(r.y), (double)cnt) : 0;
+            const int pick = scaled_index16(word_a & 0xFFFFu, cnt, max(cnt - 1, 0));   // 0 for cnt <= 1: no draw used
             int sel;
             if (M2W == 1 && opt_lorder) {
                 // inside an order window the picked rank is small (few free same-type SSEs): strip
@@ -935,7 +960,7 @@ sat_sa_kernel(const SatKernelArgs a)
             SAT_PHASE(4);                 // best tracking
             // Metropolis: accept iff expf(delta / temp) > u, via the host-built table
             // the table holds 2^32 * expf(.), compared with 2^32 * u: same decision, one multiply less
-            const float u = draw32(r.z);
+            const float u = draw32(word_b);
             // row = { 2^33 (any delta > 0: expf(x > 0) > 1 >= u), P[0], ..., P[rowmax], 0.0 (a larger
             // -delta can never be accepted) }, indexed by 1 - delta clamped to the row
             const uint32_t nd = (uint32_t)min(max(1 - delta, 0), rowmax + 2);

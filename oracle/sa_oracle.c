@@ -94,18 +94,38 @@ static void chain_begin(chain_draws *c, sa_oracle_rng *rng, uint32_t db_ordinal,
     }
 }
 
+static uint32_t chain_word(chain_draws *c, int block, int word)
+{
+    if (block != c->block_id) {
+        uint32_t counter[4] = { (uint32_t)block, 0u, c->counter_z, c->counter_w };
+        sa_oracle_philox4x32_10(counter, c->key, c->block);
+        c->block_id = block;
+    }
+    return c->block[word];
+}
+
 /* uniform float; (block, word) addresses the draw in PHILOX mode and is
  * ignored by the sequential stream */
 static float chain_draw(chain_draws *c, int block, int word)
 {
     if (c->rng->mode == SA_RNG_DRAND48)
         return (float)lcg_drand48(&c->rng->lcg);
-    if (block != c->block_id) {
-        uint32_t counter[4] = { (uint32_t)block, 0u, c->counter_z, c->counter_w };
-        sa_oracle_philox4x32_10(counter, c->key, c->block);
-        c->block_id = block;
-    }
-    return sa_oracle_u32_to_uniform(c->block[word]);
+    return sa_oracle_u32_to_uniform(chain_word(c, block, word));
+}
+
+float sa_oracle_u16_to_uniform(uint32_t v16)
+{
+    return (float)(v16 + 1u) * 1.52587890625e-05f;   /* (v + 1) * 2^-16 in (0, 1], exact */
+}
+
+/* uniform float from one 16-bit half (half 1 = high) of a Philox word: the two index draws of
+ * an SA step share a word (sa_oracle.h) */
+static float chain_draw16(chain_draws *c, int block, int word, int half)
+{
+    if (c->rng->mode == SA_RNG_DRAND48)
+        return (float)lcg_drand48(&c->rng->lcg);
+    uint32_t w = chain_word(c, block, word);
+    return sa_oracle_u16_to_uniform(half ? (w >> 16) : (w & 0xFFFFu));
 }
 
 /* ------------------------------------------------------------------ scoring */
@@ -188,7 +208,7 @@ static void random_initial_map(const sa_oracle_query *q, const uint8_t *types2, 
 /* uniformly chosen free db SSE of type `type` in [lo, hi); -1 when none.
  * No draw unless there are at least two candidates (kernel.cu:701-712). */
 static int pick_free_same_type(const uint8_t *types2, const int *revmap, int lo, int hi,
-                               uint8_t type, chain_draws *draws, int block)
+                               uint8_t type, chain_draws *draws, int block, int word)
 {
     int count = 0, only = -1;
     for (int j = lo; j < hi; j++)
@@ -198,7 +218,7 @@ static int pick_free_same_type(const uint8_t *types2, const int *revmap, int lo,
         }
     if (count == 0) return -1;
     if (count == 1) return only;
-    float u = chain_draw(draws, block, 1);
+    float u = chain_draw16(draws, block, word, 0);
     unsigned pick = (unsigned)(int)((u - SA_EPS) * count);
     for (int j = lo; j < hi; j++)
         if (types2[j] == type && revmap[j] < 0) {
@@ -265,8 +285,9 @@ void sa_oracle_search(const sa_oracle_query *q, int dbsize, const int *orders,
 
             float temp = k_temp0;
             for (int iter = 0; iter < SA_MAXITER; iter++) {
-                const int block = SA_PHILOX_STEP_BLOCK0 + iter;
-                float u = chain_draw(&draws, block, 0);
+                /* PHILOX: one block per two steps, two words per step (sa_oracle.h) */
+                const int block = SA_PHILOX_STEP_BLOCK0 + (iter >> 1), word_a = 2 * (iter & 1), word_b = word_a + 1;
+                float u = chain_draw16(&draws, block, word_a, 1);
                 int ssei = (int)((u - SA_EPS) * n1);
 
                 int startj = 0, endj = n2;
@@ -275,7 +296,7 @@ void sa_oracle_search(const sa_oracle_query *q, int dbsize, const int *orders,
                     endj = upper_bound_image(ssemap, ssei, n1, n2);
                 }
                 int newj = pick_free_same_type(types2, revmap, startj, endj,
-                                               q->ssetypes[ssei], &draws, block);
+                                               q->ssetypes[ssei], &draws, block, word_a);
                 if (sa_oracle_trace) {
                     /* same line format as the reference DEBUG build (kernel.cu:1092-1096) */
                     printf("%d %d %d %d %d %d %d\n", 0, restart, iter, ssei, startj, endj, newj);
@@ -299,7 +320,7 @@ void sa_oracle_search(const sa_oracle_query *q, int dbsize, const int *orders,
                 }
 
                 /* a Metropolis draw is consumed on every step (kernel.cu:1161-1166) */
-                u = chain_draw(&draws, block, 2);
+                u = chain_draw(&draws, block, word_b);
                 if (expf((float)delta / temp) > u) {
                     score = newscore;
                     if (oldj >= 0)

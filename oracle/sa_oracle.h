@@ -48,10 +48,14 @@ extern "C" {
  *   block b of chain (query, db entry, restart) = Philox4x32-10 with
  *     key     = (lo32(seed_q), hi32(seed_q)),  seed_q = seed + ((uint64)query << 32)
  *     counter = (b, 0, db_ordinal, restart)
- *   initial-map draw i (0 <= i < n1)  -> block i/4, word i%4
- *   SA step t (0 <= t < 100)          -> block 32+t: word 0 = which query SSE,
- *                                        word 1 = which candidate (only consumed
- *                                        when >= 2 candidates), word 2 = Metropolis
+ *   initial-map draw i (0 <= i < n1)  -> block i/4, word i%4, uniform = 2^-32 + float(v) * 2^-32
+ *   SA step t (0 <= t < 100)          -> block 32 + t/2, words a = 2*(t%2), b = a + 1:
+ *                                        word a, high 16 bits = which query SSE,
+ *                                        word a, low 16 bits  = which candidate (only consumed
+ *                                        when >= 2 candidates), each as uniform = (v16 + 1) * 2^-16;
+ *                                        word b = Metropolis, uniform = 2^-32 + float(v) * 2^-32
+ *   (one block per two steps: the index draws pick among at most 111 items, 16 bits each are
+ *   plenty; the block count is what the GPU kernel pays for)
  */
 #define SA_PHILOX_STEP_BLOCK0 32
 
@@ -78,6 +82,9 @@ void sa_oracle_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], u
 
 /* uint32 -> float in (0,1] exactly as rocrand_uniform.h:65-68 */
 float sa_oracle_u32_to_uniform(uint32_t v);
+
+/* 16-bit draw -> float in (0,1]: (v16 + 1) * 2^-16 */
+float sa_oracle_u16_to_uniform(uint32_t v16);
 
 /*
  * Search `dbsize` db structures with one query.

@@ -47,3 +47,25 @@ def test_philox_mode_is_schedule_independent():
     part, pmaps, _ = oracle_lib.search(db, qt, qd, qtypes, True, True, 32, entries=sub)
     assert np.array_equal(part, full[sub]) and np.array_equal(pmaps, fmaps[sub])
     assert full[30] == full.max() and full[30] > 20
+
+
+def test_sixteen_bit_index_draw_equals_its_integer_form():
+    """An SA step's index draws are 16-bit: u = (v + 1) * 2^-16, index = (int)((u - EPS) * n) in
+    double, the reference's expression (K.cu:1042, 710).  The GPU kernel evaluates the integer
+    ((v + 1) * n - 1) >> 16 instead (sat_sa_kernel.hpp, scaled_index16): equal for every 16-bit v and
+    every n the path can see (1..111), checked here exhaustively against the oracle's conversion."""
+    lib = oracle_lib.lib()
+    import ctypes
+    lib.sa_oracle_u16_to_uniform.restype = ctypes.c_float
+    lib.sa_oracle_u16_to_uniform.argtypes = [ctypes.c_uint32]
+    v = np.arange(65536, dtype=np.int64)
+    u = ((v + 1).astype(np.float32) * np.float32(2.0 ** -16))
+    for probe in (0, 1, 12345, 65535):
+        assert lib.sa_oracle_u16_to_uniform(probe) == u[probe]
+    assert u[0] == np.float32(2.0 ** -16) and u[-1] == 1.0
+    eps = 1.1e-7
+    for n in range(1, 112):
+        ref = ((u.astype(np.float64) - eps) * n).astype(np.int64)          # C's (int) truncation: values are >= 0
+        integer = ((v + 1) * n - 1) >> 16
+        assert np.array_equal(ref, integer), n
+        assert integer.max() == n - 1 and integer.min() == 0
