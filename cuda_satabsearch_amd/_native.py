@@ -21,11 +21,18 @@ ABI_SYMBOLS = (
     "sat_db_upload_packed", "sat_db_upload_dense", "sat_db_size", "sat_query_set", "sat_search",
     "sat_search_async", "sat_device_scores", "sat_device_ssemaps", "sat_query_order", "sat_sync",
     "sat_search_timed", "sat_use_stream", "sat_use_own_stream", "sat_results", "sat_queries_set", "sat_query_count", "sat_topk",
+    "sat_topk_hits", "sat_stat_d2h_bytes",
 )
 
 
 class SatError(RuntimeError):
     pass
+
+
+class Hit(C.Structure):
+    """struct sat_hit of include/satabsearch.h"""
+    _fields_ = [("entry", C.c_int32), ("score", C.c_int32), ("norm2", C.c_double), ("zscore", C.c_double),
+                ("pvalue", C.c_double)]
 
 
 class StructSetC(C.Structure):
@@ -75,6 +82,9 @@ def device_lib():
                                         C.c_void_p, C.c_uint32]
         lib.sat_query_count.argtypes = [C.c_void_p]
         lib.sat_topk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.sat_topk_hits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lib.sat_stat_d2h_bytes.argtypes = [C.c_void_p]
+        lib.sat_stat_d2h_bytes.restype = C.c_uint64
         lib.sat_device_scores.argtypes = [C.c_void_p]
         lib.sat_device_scores.restype = C.c_void_p
         lib.sat_device_ssemaps.argtypes = [C.c_void_p]

@@ -49,11 +49,16 @@ def build_host(force=False):
 def build_device(force=False):
     out = os.path.join(PKG, "libsatabsearch.so")
     srcs = [os.path.join(CSRC, "sat_capi.hip"), os.path.join(CSRC, "sat_topk.hip")]
-    deps = srcs + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
-                   os.path.join(INC, "satabsearch.h")]
+    # the Gumbel statistics (plain C, host libm) are linked in as well: the context tabulates them
+    # for the device-side best-k rows
+    gumbel_c = os.path.join(HOST, "sat_gumbel.c")
+    gumbel_o = os.path.join(PKG, "sat_gumbel.o")
+    deps = srcs + [gumbel_c, os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
+                   os.path.join(INC, "satabsearch.h"), os.path.join(HOST, "sat_gumbel.h")]
     if force or _stale(out, deps):
+        _run([CC, "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-I", HOST, "-c", "-o", gumbel_o, gumbel_c])
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
-              "-I", INC, "-I", CSRC, "-o", out] + srcs)
+              "-I", INC, "-I", CSRC, "-o", out] + srcs + ["-Wl," + gumbel_o, "-lm"])   # -Wl: hipcc would compile a bare .o as HIP source
     return out
 
 
@@ -74,6 +79,19 @@ def build_cli(force=False):
     return out
 
 
+def build_test_native(force=False):
+    """tests/native/*.hip: GPU-side TEST helpers (e.g. the rocRAND device API beside the kernel's own
+    Philox block).  Test infrastructure like oracle/: never loaded by the product."""
+    tdir = os.path.join(ROOT, "tests", "native")
+    src = os.path.join(tdir, "rocrand_check.hip")
+    if not os.path.exists(src):
+        return None
+    out = os.path.join(tdir, "librocrand_check.so")
+    if force or _stale(out, [src, os.path.join(CSRC, "sat_sa_kernel.hpp")]):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, "-I", CSRC, "-o", out, src])
+    return out
+
+
 def build_oracle(ref=False):
     odir = os.path.join(ROOT, "oracle")
     _run(["make", "-s", "-C", odir, "all"])
@@ -87,6 +105,7 @@ def build_all(force=False, oracle=False, ref=False):
     build_cli(force)
     if oracle:
         build_oracle(ref)
+        build_test_native(force)
 
 
 if __name__ == "__main__":

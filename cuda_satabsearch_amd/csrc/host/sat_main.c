@@ -359,6 +359,62 @@ int main(int argc, char *argv[])
                 goto bye;
             }
         }
+        if (topk > 0) {
+            /* best K per query: every GPU ranks its shard and computes the rows' statistics itself
+             * (sat_topk_hits); K rows per query and GPU come back - never the full score arrays - and the
+             * host merges the ngpu x K candidates */
+            const int kk = topk < total ? topk : total;
+            sat_hit *cand = (sat_hit *)malloc(sizeof(sat_hit) * (size_t)kk * nqb * ngpu);
+            int32_t *cand_maps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)kk * nqb * ngpu) : NULL;
+            int *got = (int *)malloc(sizeof(int) * (size_t)ngpu);
+            if (!cand || (lsoln && !cand_maps) || !got) { fprintf(stderr, "malloc failed\n"); exit(1); }
+            for (int g = 0; g < ngpu; g++) {
+                got[g] = sat_topk_hits(ctx[g], kk, cand + (size_t)g * kk * nqb, lsoln ? cand_maps + (size_t)g * kk * nqb * SAT_MAXDIM : NULL);
+                if (got[g] < 0) {
+                    fprintf(stderr, "GPU %d top-k failed: %s\n", g, sat_last_error());
+                    exit_status = 1;
+                    goto bye;
+                }
+            }
+            double ms = now_ms() - t1;
+            fprintf(stderr, "GPU execution time %f ms\n", ms);
+            fprintf(stderr, "%f million iterations/sec\n",
+                    ((double)total * nqb * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
+            for (int b = 0; b < nqb; b++) {
+                const int qs = qindex[q0 + b], n1 = n1s[b];
+                print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
+                int head[MAX_GPUS];                      /* next unprinted row of each GPU's ranked list */
+                for (int g = 0; g < ngpu; g++) head[g] = 0;
+                for (int r = 0; r < kk; r++) {
+                    int bg = -1;
+                    for (int g = 0; g < ngpu; g++) {
+                        if (head[g] >= got[g]) continue;
+                        /* GPU g's rows: got[g] per query, from cand + g * kk * nqb */
+                        const sat_hit *h = cand + (size_t)g * kk * nqb + (size_t)b * got[g] + head[g];
+                        if (bg < 0) { bg = g; continue; }
+                        const sat_hit *hb = cand + (size_t)bg * kk * nqb + (size_t)b * got[bg] + head[bg];
+                        /* ties in database order: shards are contiguous, so the lower GPU wins */
+                        if (h->score > hb->score) bg = g;
+                    }
+                    if (bg < 0) break;
+                    const size_t row = (size_t)bg * kk * nqb + (size_t)b * got[bg] + head[bg];
+                    const sat_hit *h = cand + row;
+                    const int s2 = shard_begin[bg] + h->entry;
+                    printf("%-8s %d %g %g %g\n", sat_set_name(&db, s2), h->score, h->norm2, h->zscore, h->pvalue);
+                    if (lsoln) {
+                        const int32_t *map = cand_maps + row * SAT_MAXDIM;
+                        for (int k2 = 0; k2 < n1; k2++)
+                            if (map[k2] >= 0)
+                                printf("%3d %3d\n", k2 + 1, map[k2] + 1);
+                    }
+                    head[bg]++;
+                }
+            }
+            free(cand);
+            free(cand_maps);
+            free(got);
+            continue;
+        }
         for (int g = 0; g < ngpu; g++) {
             const int sb = shard_begin[g], sn = shard_begin[g + 1] - sb;
             if (sat_results(ctx[g], lsoln, shard_scores, shard_maps) != SAT_OK) {
@@ -377,43 +433,6 @@ int main(int argc, char *argv[])
         fprintf(stderr, "GPU execution time %f ms\n", ms);
         fprintf(stderr, "%f million iterations/sec\n",
                 ((double)total * nqb * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
-        if (topk > 0) {
-            /* best K per query: each GPU ranks its shard, the host merges ngpu x K candidates */
-            const int kk = topk < total ? topk : total;
-            int32_t *cand_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk * ngpu);
-            int32_t *cand_sc = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk * ngpu);
-            if (!cand_idx || !cand_sc) { fprintf(stderr, "malloc failed\n"); exit(1); }
-            for (int b = 0; b < nqb; b++) {
-                const int qs = qindex[q0 + b], n1 = n1s[b];
-                int nc = 0;
-                for (int g = 0; g < ngpu; g++) {
-                    int got = sat_topk(ctx[g], b, kk, cand_idx + nc, cand_sc + nc);
-                    if (got < 0) {
-                        fprintf(stderr, "GPU %d top-k failed: %s\n", g, sat_last_error());
-                        exit_status = 1;
-                        goto bye;
-                    }
-                    for (int i = 0; i < got; i++) cand_idx[nc + i] += shard_begin[g];
-                    nc += got;
-                }
-                print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
-                for (int r = 0; r < kk && r < nc; r++) {          /* selection of the merged head */
-                    int bestc = r;
-                    for (int c2 = r + 1; c2 < nc; c2++)
-                        if (cand_sc[c2] > cand_sc[bestc] || (cand_sc[c2] == cand_sc[bestc] && cand_idx[c2] < cand_idx[bestc]))
-                            bestc = c2;
-                    int32_t ti = cand_idx[r], ts = cand_sc[r];
-                    cand_idx[r] = cand_idx[bestc]; cand_sc[r] = cand_sc[bestc];
-                    cand_idx[bestc] = ti; cand_sc[bestc] = ts;
-                    const int s2 = cand_idx[r];
-                    print_row(sat_set_name(&db, s2), cand_sc[r], n1, db.order[s2],
-                              ssemaps ? ssemaps + ((size_t)b * total + s2) * SAT_MAXDIM : NULL, lsoln, 0);
-                }
-            }
-            free(cand_idx);
-            free(cand_sc);
-            continue;
-        }
         for (int b = 0; b < nqb; b++) {
             const int qi = q0 + b, qs = qindex[qi], n1 = n1s[b];
             const int32_t *qscores = scores + (size_t)b * total;
@@ -444,6 +463,11 @@ int main(int argc, char *argv[])
             }
         }
 bye:
+    {
+        unsigned long long copied = 0;
+        for (int g = 0; g < ngpu; g++) copied += sat_stat_d2h_bytes(ctx[g]);
+        fprintf(stderr, "copied %llu bytes of results from the GPU(s)\n", copied);
+    }
     for (int g = 0; g < ngpu; g++)
         sat_ctx_destroy(ctx[g]);
     (void)cltype; (void)clorder; (void)clsoln;

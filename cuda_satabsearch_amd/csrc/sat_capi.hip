@@ -20,6 +20,7 @@
 #include "satabsearch.h"
 #include "sat_sa_kernel.hpp"
 #include "sat_ctx.hpp"
+#include "host/sat_gumbel.h"
 
 namespace {
 
@@ -103,6 +104,23 @@ int build_metropolis_table(sat_ctx *ctx)
     HIP_TRY(hipMalloc(&ctx->d_prow, rows.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(ctx->d_ptab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_prow, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return SAT_OK;
+}
+
+int build_gumbel_tables(sat_ctx *ctx)
+{
+    // the reference computes z from the norm2 score TRUNCATED TO AN INT (gumbelstats.h:26 vs H.cu:446),
+    // so z and p take one value per integer: tabulated here with the host's libm for x = -128 .. 127
+    // (|norm2| <= 110), the device's best-k rows look them up (sat_topk.hip)
+    double z[256], p[256];
+    for (int x = -128; x < 128; x++) {
+        z[x + 128] = sat_z_gumbel_trunc((double)x);
+        p[x + 128] = sat_pv_gumbel(z[x + 128]);
+    }
+    HIP_TRY(hipMalloc(&ctx->d_gumbel_z, sizeof z));
+    HIP_TRY(hipMalloc(&ctx->d_gumbel_p, sizeof p));
+    HIP_TRY(hipMemcpy(ctx->d_gumbel_z, z, sizeof z, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_gumbel_p, p, sizeof p, hipMemcpyHostToDevice));
     return SAT_OK;
 }
 
@@ -507,7 +525,8 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
             }
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         }
-        return build_metropolis_table(ctx);
+        const int rc_tab = build_metropolis_table(ctx);
+        return rc_tab != SAT_OK ? rc_tab : build_gumbel_tables(ctx);
     };
     if (init() != SAT_OK) {
         sat_ctx_destroy(ctx);
@@ -527,6 +546,15 @@ void sat_ctx_destroy(sat_ctx *ctx)
     dev_free(ctx->d_bmap_slabs);
     dev_free(ctx->d_ptab);
     dev_free(ctx->d_prow);
+    dev_free(ctx->d_keys);
+    dev_free(ctx->d_sorted);
+    dev_free(ctx->d_sort_temp);
+    dev_free(ctx->d_hitq);
+    dev_free(ctx->d_seg);
+    dev_free(ctx->d_hits);
+    dev_free(ctx->d_hit_maps);
+    dev_free(ctx->d_gumbel_z);
+    dev_free(ctx->d_gumbel_p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -803,6 +831,8 @@ void *sat_device_scores(sat_ctx *ctx) { return ctx ? ctx->d_scores : nullptr; }
 void *sat_device_ssemaps(sat_ctx *ctx) { return ctx ? ctx->d_ssemaps : nullptr; }
 int sat_query_order(const sat_ctx *ctx) { return (ctx && !ctx->queries.empty()) ? ctx->queries[0].n1 : 0; }
 
+unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx) { return ctx ? ctx->d2h_bytes : 0ull; }
+
 int sat_sync(sat_ctx *ctx)
 {
     if (!ctx) return fail(SAT_EINVAL, "null context");
@@ -823,6 +853,7 @@ int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t nq = ctx->queries.size(), N = (size_t)ctx->n_entries;
     HIP_TRY(hipMemcpy(scores, ctx->d_scores, nq * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    ctx->d2h_bytes += nq * N * sizeof(int32_t);
     if (lsoln) {
         if (!ctx->d_ssemaps || !ctx->searched_lsoln) return fail(SAT_ESTATE, "the last search ran without lsoln");
         std::vector<int8_t> packed;
@@ -830,6 +861,7 @@ int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps)
             const auto &q = ctx->queries[qi];
             packed.resize(N * q.n1);
             HIP_TRY(hipMemcpy(packed.data(), ctx->d_ssemaps + q.ssemap_off, packed.size(), hipMemcpyDeviceToHost));
+            ctx->d2h_bytes += packed.size();
             int32_t *out = ssemaps + qi * N * SAT_MAXDIM;
             for (size_t e = 0; e < N; e++)
                 for (int i = 0; i < q.n1; i++)

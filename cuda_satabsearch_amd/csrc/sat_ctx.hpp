@@ -66,6 +66,23 @@ struct sat_ctx {
     size_t ssemaps_cap = 0;
     uint32_t *d_bmap_slabs = nullptr;        // LSOLN scratch: one best-map slab per workgroup of a launch
     size_t bmap_slabs_cap = 0;               // in 32-bit words
+
+    // best-k selection (sat_topk.hip): context-owned scratch that only grows; capacities in elements
+    unsigned long long *d_keys = nullptr, *d_sorted = nullptr;
+    size_t keys_cap = 0, sorted_cap = 0;
+    unsigned char *d_sort_temp = nullptr, *d_hitq = nullptr;
+    size_t sort_temp_cap = 0, hitq_cap = 0;
+    int *d_seg = nullptr;
+    size_t seg_cap = 0;
+    sat_hit *d_hits = nullptr;
+    size_t hits_cap = 0;
+    int32_t *d_hit_maps = nullptr;
+    size_t hit_maps_cap = 0;
+    // z and p of every truncated norm2 score -128 .. 127, computed by the HOST's libm (sat_gumbel.c)
+    double *d_gumbel_z = nullptr, *d_gumbel_p = nullptr;
+
+    // bytes copied device -> host by this context's result calls (sat_stat_d2h_bytes)
+    unsigned long long d2h_bytes = 0;
 };
 
 

@@ -655,8 +655,9 @@ sat_sa_kernel(const SatKernelArgs a)
                 for (int s = 0; s < 4; s++) {
                     const int i = i0 + s;
                     if (i < n1) {
-                        float u = to_uniform(rv[s]);
-                        if (!stopped && u < 0.5f) {
+                        // u < 0.5 for u = 2^-32 + float(v) * 2^-32 (K.cu:625): float(v) < 2^31, i.e. v below the
+                        // first value that rounds up to 2^31 (24-bit mantissa, ties to even)
+                        if (!stopped && rv[s] < 0x7FFFFFC0u) {
                             const int t = qtypes[i];
                             Bits<M2W> cand, below = bits_below<M2W>(j);
 #pragma unroll

@@ -177,6 +177,26 @@ class Searcher:
             self._check(n)
         return idx[:n], sc[:n]
 
+    def topk_hits(self, k, lsoln=False):
+        """Best-k rows of every query of the last search, ranked on the device with their statistics:
+        a structured array [nq, k'] with fields entry, score, norm2, zscore, pvalue (and the rows'
+        solution maps int32[nq, k', 111] when lsoln)."""
+        nq = getattr(self, "n_queries", 1)
+        k = min(int(k), self.n_entries)
+        dt = np.dtype([("entry", np.int32), ("score", np.int32), ("norm2", np.float64), ("zscore", np.float64),
+                       ("pvalue", np.float64)], align=True)
+        assert dt.itemsize == C.sizeof(_native.Hit)
+        hits = np.zeros((nq, k), dt)
+        maps = np.full((nq, k, MAXDIM), -1, np.int32) if lsoln else None
+        n = self._lib.sat_topk_hits(self._ctx, k, hits.ctypes.data, maps.ctypes.data if lsoln else None)
+        if n < 0:
+            self._check(n)
+        return (hits, maps) if lsoln else hits
+
+    def d2h_bytes(self):
+        """Bytes this context's result calls have copied device -> host so far."""
+        return int(self._lib.sat_stat_d2h_bytes(self._ctx))
+
     def sync(self):
         self._check(self._lib.sat_sync(self._ctx))
 

@@ -197,6 +197,33 @@ int sat_results(sat_ctx *ctx, int lsoln, int32_t *scores, int32_t *ssemaps);
 int sat_topk(sat_ctx *ctx, int query, int k, int32_t *entry_index, int32_t *scores_out);
 
 /*
+ * One row of the reference's output, "name rawscore norm2score z-score p-value"
+ * (cudaSaTabsearch.cu:445-453), for a best-k hit: the entry's index in the shard instead of its name.
+ */
+typedef struct sat_hit {
+    int32_t entry;      /* index in the resident shard                                            */
+    int32_t score;      /* raw score                                                              */
+    double  norm2;      /* 2 * score / (n1 + n2)                         gumbelstats.c:91-94      */
+    double  zscore;     /* Gumbel z of the norm2 score truncated to an int   gumbelstats.c:50-58  */
+    double  pvalue;     /* 1 - exp(-exp(-(pi / sqrt 6 * z + gamma)))      gumbelstats.c:69-72     */
+} sat_hit;
+
+/*
+ * Best-k rows of EVERY query of the last search, ranked and given their statistics on the device
+ * (one segmented sort for the whole batch; the statistics are bit-identical to the host's
+ * csrc/host/sat_gumbel.c): hits[q * k + r] is rank r of query q, by descending score, ties in
+ * database order.  ssemaps (may be NULL): [n_queries * k * SAT_MAXDIM] solution maps of those rows,
+ * laid out like sat_search's, after a search with lsoln.  Only these k rows per query are copied
+ * to the host - what a user who pipes the reference's output through `sort -k 2,2nr | head`
+ * wants (README_example_usage.txt:100, 256).  Returns min(k, n_entries) or a negative SAT_E* code.
+ */
+int sat_topk_hits(sat_ctx *ctx, int k, sat_hit *hits, int32_t *ssemaps);
+
+/* Bytes this context's result calls (sat_results, sat_search, sat_topk, sat_topk_hits) have copied
+ * from the device to the host since it was created (diagnostics: the best-k path moves O(k) rows). */
+unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx);
+
+/*
  * Time `repeats` back-to-back searches with HIP events on the launch stream
  * (inputs resident, no copies inside the window).  Returns total milliseconds
  * in *total_ms and the dominant SA kernel's summed device time in *kernel_ms.

@@ -20,6 +20,7 @@ def _native_built():
     build.build_host()
     build.build_device()
     build.build_cli()
+    build.build_test_native()
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
     yield
 

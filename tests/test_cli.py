@@ -112,3 +112,35 @@ def test_gpu_mode_topk_is_sorted_head_of_full_output(golden_dir):
         rows = sorted(enumerate(b["rows"]), key=lambda t: (-int(t[1].split()[1]), t[0]))[:7]
         expect += b["head"] + [r for _, r in rows]
     assert top.stdout.decode().splitlines() == expect
+
+
+@pytest.mark.gpu
+def test_gpu_mode_topk_never_downloads_the_score_arrays(tmp_path):
+    """-k 10 over a 100 000-entry database with a 3-SID query list and solution maps off: the rows
+    printed are the sorted head of the full output, and the bytes copied from the GPU are 10 rows per
+    query (32 B each) where the full listing copies 400 KB per query."""
+    db = sat.synth.make_db(100_000, 8, 32, sort=True, name_format="s%06d")
+    db.write_ascii(tmp_path / "db.ascii")
+    sids = (db.names[99_999] + "\n" + db.names[50_000] + "\n" + db.names[7] + "\n").encode()
+    top = run(CLI, str(tmp_path), ["-r", "64", "-k", "10", "-q", "db.ascii"], stdin_bytes=sids)
+    assert top.returncode == 0, top.stderr.decode()[-300:]
+    copied = [int(l.split()[1]) for l in top.stderr.decode().splitlines() if l.startswith("copied ")]
+    assert copied == [3 * 10 * 32]
+    full = run(CLI, str(tmp_path), ["-r", "64", "-q", "db.ascii"], stdin_bytes=sids)
+    assert full.returncode == 0
+    copied_full = [int(l.split()[1]) for l in full.stderr.decode().splitlines() if l.startswith("copied ")]
+    assert copied_full == [3 * 100_000 * 4]
+    blocks, cur = [], None
+    for line in full.stdout.decode().splitlines():
+        if line.startswith("# cudaSaTabsearch"):
+            cur = {"head": [line], "rows": []}
+            blocks.append(cur)
+        elif line.startswith("#"):
+            cur["head"].append(line)
+        else:
+            cur["rows"].append(line)
+    expect = []
+    for b in blocks:
+        rows = sorted(enumerate(b["rows"]), key=lambda t: (-int(t[1].split()[1]), t[0]))[:10]
+        expect += b["head"] + [r for _, r in rows]
+    assert top.stdout.decode().splitlines() == expect

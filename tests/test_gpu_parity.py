@@ -267,6 +267,60 @@ def test_device_topk(searcher, small_db, golden_dir):
     assert len(idx) == len(small_db) and (np.diff(sc) <= 0).all()
 
 
+def test_device_topk_rows_carry_the_hosts_statistics(searcher, small_db, golden_dir):
+    """sat_topk_hits: the best k rows of EVERY query of a batch from one segmented sort, with norm2 /
+    z / p computed on the device - bit-identical to csrc/host/sat_gumbel.c (z from the norm2 score
+    truncated to an int, as the reference does) - and the rows' solution maps after an LSOLN search."""
+    from cuda_satabsearch_amd import _native
+    host = _native.host_lib()
+    qs = [load_query(golden_dir, "d2phlb1.input"), load_query(golden_dir, "multiquery.input", 0),
+          load_query(golden_dir, "multiquery.input", 2)]                    # 19, 8 and 101 SSEs
+    searcher.upload(small_db)
+    searcher.set_queries(qs)
+    scores, maps, _ = searcher.search(True, True, 128)
+    k = 12
+    hits, hmaps = searcher.topk_hits(k, lsoln=True)
+    assert hits.shape == (3, k) and hmaps.shape == (3, k, 111)
+    n = len(small_db)
+    for qi, q in enumerate(qs):
+        n1 = len(q[2])
+        order = np.lexsort((np.arange(n), -scores[qi].astype(np.int64)))[:k]
+        assert np.array_equal(hits[qi]["entry"], order) and np.array_equal(hits[qi]["score"], scores[qi][order])
+        for r, e in enumerate(order):
+            norm2 = host.sat_norm2(int(scores[qi][e]), n1, int(small_db.orders[e]))
+            z = host.sat_z_gumbel_trunc(norm2)
+            # bit for bit: compare the doubles' bytes, not their values
+            assert np.float64(norm2).tobytes() == hits[qi]["norm2"][r].tobytes()
+            assert np.float64(z).tobytes() == hits[qi]["zscore"][r].tobytes()
+            assert np.float64(host.sat_pv_gumbel(z)).tobytes() == hits[qi]["pvalue"][r].tobytes()
+        assert np.array_equal(hmaps[qi], maps[qi][order])
+    # negative and fractional norm2 scores exercise the truncation toward zero
+    assert (hits["norm2"] < 1.0).any() and (hits["norm2"] > 1.0).any()
+    with pytest.raises(sat.SatError, match="without lsoln"):
+        searcher.search_async(True, False, 64)
+        searcher.topk_hits(3, lsoln=True)
+
+
+def test_topk_download_is_k_rows_per_query():
+    """After a search of 100 000 entries the best-10 path copies 10 rows per query to the host
+    (32 bytes each), not the 400 KB score array: the context's own byte counter is the witness."""
+    db = sat.synth.make_db(100_000, 8, 32, sort=True)
+    qs = [sat.synth.make_query(32), sat.synth.make_query(16), sat.synth.planted_query(db, 70_000)]
+    with sat.Searcher(0) as s:
+        s.upload(db)
+        s.set_queries(qs)
+        s.search_async(True, False, 64)
+        before = s.d2h_bytes()
+        hits = s.topk_hits(10)
+        assert s.d2h_bytes() - before == 3 * 10 * 32
+        full, _ = s.results()
+        assert s.d2h_bytes() - before == 3 * 10 * 32 + 3 * 100_000 * 4
+    for qi in range(3):
+        order = np.lexsort((np.arange(len(db)), -full[qi].astype(np.int64)))[:10]
+        assert np.array_equal(hits[qi]["entry"], order)
+    assert hits[2]["entry"][0] == 70_000
+
+
 # ---------------------------------------------------------------- edge cases
 def test_degenerate_structures(searcher):
     """1-SSE structures, a query whose SSE types do not occur in an entry, all-'??' codes."""
@@ -550,3 +604,34 @@ def test_full_size_properties():
     osc, _, _ = oracle_lib.search(db, *q, True, False, 128, entries=sample)
     assert np.array_equal(a[sample], osc)
     print(f"100k x 32-SSE: {ms:.1f} ms -> {n / ms * 1e3:.0f} scorings/s")
+
+
+# ---------------------------------------------------------------- the random stream and rocRAND
+def test_philox_block_is_rocrands_block():
+    """The kernel writes its Philox4x32-10 block out by hand (sat_sa_kernel.hpp, philox_block); the
+    claim that it is the block rocRAND's device API returns for rocrand_init(seed, subsequence,
+    4 * block) + rocrand4() - and that its uniform conversion is rocrand_uniform's - is checked here on
+    the device, both sides in one kernel (tests/native/rocrand_check.hip), for random and edge-case
+    (seed, subsequence, block) triples, including the ones the search uses: seed + (query << 32),
+    subsequence = db ordinal | restart << 32, block = SSE group or 32 + step pair."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "native", "librocrand_check.so"))
+    rng = np.random.default_rng(7)
+    n = 20_000
+    seed = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    sub = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    block = rng.integers(0, 2 ** 30, n, dtype=np.uint64).astype(np.uint32)
+    # the search's own addressing
+    k = n // 2
+    seed[:k] = 1234 + (rng.integers(0, 300, k).astype(np.uint64) << np.uint64(32))
+    sub[:k] = rng.integers(0, 1_000_000, k).astype(np.uint64) | (rng.integers(0, 4096, k).astype(np.uint64) << np.uint64(32))
+    block[:k] = rng.integers(0, 82, k).astype(np.uint32)
+    # edges
+    seed[-4:] = [0, 2 ** 64 - 1, 1234, 1234]
+    sub[-4:] = [0, 2 ** 64 - 1, 2 ** 32 - 1, 2 ** 32]
+    block[-4:] = [0, 2 ** 30 - 1, 0, 81]
+    ours = (ctypes.c_uint32 * 4)()
+    theirs = (ctypes.c_uint32 * 4)()
+    bad = lib.sat_test_philox_vs_rocrand(n, seed.ctypes.data_as(ctypes.c_void_p), sub.ctypes.data_as(ctypes.c_void_p),
+                                         block.ctypes.data_as(ctypes.c_void_p), ours, theirs)
+    assert bad == 0, f"{bad} of {n} blocks differ from rocRAND's; first: ours {list(ours)} rocRAND {list(theirs)}"

@@ -69,3 +69,11 @@ def test_sixteen_bit_index_draw_equals_its_integer_form():
         integer = ((v + 1) * n - 1) >> 16
         assert np.array_equal(ref, integer), n
         assert integer.max() == n - 1 and integer.min() == 0
+
+
+def test_initial_map_draw_threshold_in_integers():
+    """thinit matches a query SSE when u < 0.5 (K.cu:625); for u = 2^-32 + float(v) * 2^-32 that is
+    v < 0x7FFFFFC0 (float(v) rounds to 2^31 from there on): the form the kernel tests."""
+    f = oracle_lib.lib().sa_oracle_u32_to_uniform
+    for v in list(range(0x7FFFFF00, 0x80000100)) + [0, 1, 0x3FFFFFFF, 0x7FFFFFBF, 0x7FFFFFC0, 0xFFFFFFFF]:
+        assert (f(v) < 0.5) == (v < 0x7FFFFFC0), hex(v)
