@@ -12,14 +12,17 @@ HOST     = $(CSRC)/host
 
 all: $(PKG)/libsathost.so $(PKG)/libsatabsearch.so $(PKG)/bin/satabsearch
 
-$(PKG)/libsathost.so: $(HOST)/sat_parse.c $(HOST)/sat_gumbel.c $(HOST)/sat_parse.h $(HOST)/sat_gumbel.h
-	$(CC) -O2 -fPIC -shared -Wall -Wextra -I$(HOST) -o $@ $(HOST)/sat_parse.c $(HOST)/sat_gumbel.c -lm
+$(PKG)/libsathost.so: $(HOST)/sat_parse.c $(HOST)/sat_gumbel.c $(HOST)/sat_shard.c $(HOST)/sat_parse.h $(HOST)/sat_gumbel.h $(HOST)/sat_shard.h
+	$(CC) -O2 -fPIC -shared -Wall -Wextra -I$(HOST) -o $@ $(HOST)/sat_parse.c $(HOST)/sat_gumbel.c $(HOST)/sat_shard.c -lm
+
+$(PKG)/sat_shard.o: $(HOST)/sat_shard.c $(HOST)/sat_shard.h
+	$(CC) -O2 -fPIC -ffp-contract=off -Wall -Wextra -I$(HOST) -c -o $@ $(HOST)/sat_shard.c
 
 $(PKG)/sat_gumbel.o: $(HOST)/sat_gumbel.c $(HOST)/sat_gumbel.h
 	$(CC) -O2 -fPIC -ffp-contract=off -Wall -Wextra -I$(HOST) -c -o $@ $(HOST)/sat_gumbel.c
 
-$(PKG)/libsatabsearch.so: $(CSRC)/sat_capi.hip $(CSRC)/sat_topk.hip $(PKG)/sat_gumbel.o $(CSRC)/sat_sa_kernel.hpp $(CSRC)/sat_ctx.hpp include/satabsearch.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared -Iinclude -I$(CSRC) -o $@ $(CSRC)/sat_capi.hip $(CSRC)/sat_topk.hip -Wl,$(PKG)/sat_gumbel.o -lm
+$(PKG)/libsatabsearch.so: $(CSRC)/sat_capi.hip $(CSRC)/sat_topk.hip $(CSRC)/sat_multi.hip $(PKG)/sat_gumbel.o $(PKG)/sat_shard.o $(CSRC)/sat_sa_kernel.hpp $(CSRC)/sat_ctx.hpp include/satabsearch.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared -Iinclude -I$(CSRC) -o $@ $(CSRC)/sat_capi.hip $(CSRC)/sat_topk.hip $(CSRC)/sat_multi.hip -Wl,$(PKG)/sat_gumbel.o -Wl,$(PKG)/sat_shard.o -lm -ldl
 
 $(PKG)/bin/satabsearch: $(HOST)/sat_main.c $(HOST)/sat_host_search.c $(PKG)/libsatabsearch.so $(PKG)/libsathost.so
 	mkdir -p $(PKG)/bin

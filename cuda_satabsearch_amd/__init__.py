@@ -8,5 +8,5 @@ formatting and the seeded synthetic database generator.
 """
 from ._native import SatError, ABI_SYMBOLS  # noqa: F401
 from .structures import StructSet, MAXDIM, MAXDIM_SMALL  # noqa: F401
-from .search import Searcher, device_count, DEFAULT_MAXSTART, DEFAULT_SEED  # noqa: F401
-from . import report, sharding, synth  # noqa: F401
+from .search import Searcher, MultiSearcher, device_count, DEFAULT_MAXSTART, DEFAULT_SEED  # noqa: F401
+from . import report, sharding, synth, workloads  # noqa: F401

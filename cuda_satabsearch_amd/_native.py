@@ -22,6 +22,8 @@ ABI_SYMBOLS = (
     "sat_search_async", "sat_device_scores", "sat_device_ssemaps", "sat_query_order", "sat_sync",
     "sat_search_timed", "sat_use_stream", "sat_use_own_stream", "sat_results", "sat_queries_set", "sat_query_count", "sat_topk",
     "sat_topk_hits", "sat_stat_d2h_bytes",
+    "sat_multi_create", "sat_multi_destroy", "sat_multi_device_count", "sat_multi_gather_kind", "sat_multi_db_upload_packed",
+    "sat_multi_shards", "sat_multi_queries_set", "sat_multi_search", "sat_multi_search_topk", "sat_multi_stat_d2h_bytes",
 )
 
 
@@ -85,6 +87,21 @@ def device_lib():
         lib.sat_topk_hits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.sat_stat_d2h_bytes.argtypes = [C.c_void_p]
         lib.sat_stat_d2h_bytes.restype = C.c_uint64
+        lib.sat_multi_create.restype = C.c_void_p
+        lib.sat_multi_create.argtypes = [C.c_int, C.c_void_p, C.c_uint64]
+        lib.sat_multi_destroy.argtypes = [C.c_void_p]
+        lib.sat_multi_destroy.restype = None
+        lib.sat_multi_device_count.argtypes = [C.c_void_p]
+        lib.sat_multi_gather_kind.argtypes = [C.c_void_p]
+        lib.sat_multi_gather_kind.restype = C.c_char_p
+        lib.sat_multi_db_upload_packed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.sat_multi_shards.argtypes = [C.c_void_p, C.c_void_p]
+        lib.sat_multi_queries_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
+        lib.sat_multi_search.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        lib.sat_multi_search_topk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_double)]
+        lib.sat_multi_stat_d2h_bytes.argtypes = [C.c_void_p]
+        lib.sat_multi_stat_d2h_bytes.restype = C.c_uint64
         lib.sat_device_scores.argtypes = [C.c_void_p]
         lib.sat_device_scores.restype = C.c_void_p
         lib.sat_device_ssemaps.argtypes = [C.c_void_p]
@@ -123,6 +140,9 @@ def host_lib():
         lib.sat_z_gumbel_trunc.restype = C.c_double
         lib.sat_pv_gumbel.argtypes = [C.c_double]
         lib.sat_pv_gumbel.restype = C.c_double
+        lib.sat_entry_cost.argtypes = [C.c_int]
+        lib.sat_entry_cost.restype = C.c_double
+        lib.sat_shard_cuts.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _host = lib
     return _host
 

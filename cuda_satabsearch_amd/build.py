@@ -39,8 +39,8 @@ def _stale(target, sources):
 
 def build_host(force=False):
     out = os.path.join(PKG, "libsathost.so")
-    srcs = [os.path.join(HOST, f) for f in ("sat_parse.c", "sat_gumbel.c")]
-    deps = srcs + [os.path.join(HOST, f) for f in ("sat_parse.h", "sat_gumbel.h")]
+    srcs = [os.path.join(HOST, f) for f in ("sat_parse.c", "sat_gumbel.c", "sat_shard.c")]
+    deps = srcs + [os.path.join(HOST, f) for f in ("sat_parse.h", "sat_gumbel.h", "sat_shard.h")]
     if force or _stale(out, deps):
         _run([CC, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", HOST, "-o", out] + srcs + ["-lm"])
     return out
@@ -48,17 +48,19 @@ def build_host(force=False):
 
 def build_device(force=False):
     out = os.path.join(PKG, "libsatabsearch.so")
-    srcs = [os.path.join(CSRC, "sat_capi.hip"), os.path.join(CSRC, "sat_topk.hip")]
-    # the Gumbel statistics (plain C, host libm) are linked in as well: the context tabulates them
-    # for the device-side best-k rows
-    gumbel_c = os.path.join(HOST, "sat_gumbel.c")
-    gumbel_o = os.path.join(PKG, "sat_gumbel.o")
-    deps = srcs + [gumbel_c, os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
-                   os.path.join(INC, "satabsearch.h"), os.path.join(HOST, "sat_gumbel.h")]
+    srcs = [os.path.join(CSRC, "sat_capi.hip"), os.path.join(CSRC, "sat_topk.hip"), os.path.join(CSRC, "sat_multi.hip")]
+    # plain-C host pieces linked in as well: the Gumbel statistics (the context tabulates them with the
+    # host libm for the device-side best-k rows) and the shard cost model (multi-GPU cuts)
+    host_c = [os.path.join(HOST, "sat_gumbel.c"), os.path.join(HOST, "sat_shard.c")]
+    host_o = [os.path.join(PKG, "sat_gumbel.o"), os.path.join(PKG, "sat_shard.o")]
+    deps = srcs + host_c + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
+                            os.path.join(INC, "satabsearch.h"), os.path.join(HOST, "sat_gumbel.h"), os.path.join(HOST, "sat_shard.h")]
     if force or _stale(out, deps):
-        _run([CC, "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-I", HOST, "-c", "-o", gumbel_o, gumbel_c])
+        for c, o in zip(host_c, host_o):
+            _run([CC, "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-I", HOST, "-c", "-o", o, c])
+        # -Wl,: hipcc would compile a bare .o as HIP source.  librccl is NOT linked: sat_multi.hip loads it on demand
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
-              "-I", INC, "-I", CSRC, "-o", out] + srcs + ["-Wl," + gumbel_o, "-lm"])   # -Wl: hipcc would compile a bare .o as HIP source
+              "-I", INC, "-I", CSRC, "-o", out] + srcs + ["-Wl," + o for o in host_o] + ["-lm", "-ldl"])
     return out
 
 

@@ -11,9 +11,10 @@
  *
  * Host code is plain C; the search itself goes through the C ABI of
  * include/satabsearch.h (HIP kernel).  The reference is single-GPU (its TODO, :790);
- * here the database is sharded contiguously over the visible GPUs (-g N), one context
- * per GPU driven from this thread: launch on all, then collect in file order.  Results
- * do not depend on N (the random streams are keyed by db ordinal).
+ * here the database is sharded contiguously, by cost, over the visible GPUs (-g N) behind
+ * the sat_multi_* entry points: launch on all, one RCCL gather to device 0, one copy to
+ * the host, rows in file order.  Results do not depend on N (the random streams are keyed
+ * by db ordinal).
  *
  * -c selects the host mode (csrc/host/sat_host_search.c): one CPU thread, one
  * sequential drand48 stream, byte-identical to the reference's -c.  It is never a
@@ -38,7 +39,6 @@
 #include "sat_host_search.h"
 #include "sat_parse.h"
 
-#define MAX_GPUS 64
 
 static double now_ms(void)
 {
@@ -267,42 +267,34 @@ int main(int argc, char *argv[])
     fprintf(stderr, "found %d HIP devices\n", ndev);
     int ngpu = want_gpus > 0 ? want_gpus : ndev;
     if (ngpu > ndev) ngpu = ndev;
-    if (ngpu > MAX_GPUS) ngpu = MAX_GPUS;
     if (ngpu > total) ngpu = total;
 
-    /* contiguous shards of the file order, equal entry counts (the cost of an entry is
-     * dominated by the query size, not the entry size) */
-    sat_ctx *ctx[MAX_GPUS];
-    int shard_begin[MAX_GPUS + 1];
-    int64_t *ordinal = (int64_t *)malloc(sizeof(int64_t) * (size_t)total);
-    for (int s = 0; s < total; s++) ordinal[s] = s;
+    /* One multi-GPU context: the database is cut into contiguous shards of equal COST (entries of a
+     * size-sorted database differ several-fold in cost, sat_shard.h), every GPU holds its shard, a
+     * search is queued on all of them and one gather (RCCL over xGMI) brings the rows to device 0. */
     t0 = now_ms();
-    for (int g = 0; g <= ngpu; g++)
-        shard_begin[g] = (int)((int64_t)total * g / ngpu);
-    for (int g = 0; g < ngpu; g++) {
-        ctx[g] = sat_ctx_create(g, seed);
-        if (!ctx[g]) {
-            fprintf(stderr, "sat_ctx_create(%d) failed: %s\n", g, sat_last_error());
-            exit(1);
-        }
-        int b = shard_begin[g], n = shard_begin[g + 1] - b;
-        /* a shard is a window of the packed arrays: rebase its cell offsets to the window */
-        int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
-        if (!off) { fprintf(stderr, "malloc failed\n"); exit(1); }
-        for (int e = 0; e < n; e++) off[e] = db.cell_off[b + e] - db.cell_off[b];
-        int rc = sat_db_upload_packed(ctx[g], n, db.order + b, off, db.tab + db.cell_off[b],
-                                      db.dist + db.cell_off[b], ordinal + b);
-        free(off);
-        if (rc != SAT_OK) {
-            fprintf(stderr, "database upload to GPU %d failed: %s\n", g, sat_last_error());
-            exit(1);
-        }
+    sat_multi *multi = sat_multi_create(ngpu, NULL, seed);
+    if (!multi) {
+        fprintf(stderr, "sat_multi_create(%d) failed: %s\n", ngpu, sat_last_error());
+        exit(1);
     }
-    fprintf(stderr, "Copied %d entries to %d GPU(s) in %f ms\n", total, ngpu, now_ms() - t0);
+    if (sat_multi_db_upload_packed(multi, total, db.order, db.cell_off, db.tab, db.dist) != SAT_OK) {
+        fprintf(stderr, "database upload failed: %s\n", sat_last_error());
+        exit(1);
+    }
+    fprintf(stderr, "Copied %d entries to %d GPU(s) in %f ms (gather: %s)\n", total, ngpu, now_ms() - t0,
+            sat_multi_gather_kind(multi));
+    if (ngpu > 1) {
+        int32_t *begin = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ngpu + 1));
+        if (begin && sat_multi_shards(multi, begin) == SAT_OK)
+            for (int g = 0; g < ngpu; g++)
+                fprintf(stderr, "  GPU %d: entries %d .. %d\n", g, begin[g], begin[g + 1] - 1);
+        free(begin);
+    }
 
     /* rows of the large class are printed after every query's small-class block */
     int32_t *large_scores = NULL, *large_maps = NULL;
-    if (cls_count[1] > 0) {
+    if (cls_count[1] > 0 && topk <= 0) {
         large_scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)cls_count[1] * num_queries);
         if (lsoln) large_maps = (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)cls_count[1] * num_queries);
         if (!large_scores || (lsoln && !large_maps)) { fprintf(stderr, "malloc failed\n"); exit(1); }
@@ -312,27 +304,35 @@ int main(int argc, char *argv[])
      * entries x queries), which is what fills the machine when the database is small and the
      * query list long (-q).  The batch size is bounded by the host result buffers. */
     int batch = 256;
-    {
+    if (topk <= 0) {
         const size_t per_query = (size_t)total * (lsoln ? (SAT_MAXDIM + 1) : 1) * sizeof(int32_t);
         const size_t budget = (size_t)1 << 30;
         if ((size_t)batch * per_query > budget) batch = (int)(budget / per_query);
-        if (batch < 1) batch = 1;
-        if (batch > num_queries) batch = num_queries;
     }
+    if (batch < 1) batch = 1;
+    if (batch > num_queries) batch = num_queries;
     free(scores);
     free(ssemaps);
-    scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)total * batch);
-    ssemaps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)total * batch) : NULL;
-    int max_shard = 0;
-    for (int g = 0; g < ngpu; g++)
-        if (shard_begin[g + 1] - shard_begin[g] > max_shard) max_shard = shard_begin[g + 1] - shard_begin[g];
-    int32_t *shard_scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_shard * batch);
-    int32_t *shard_maps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)max_shard * batch) : NULL;
+    scores = NULL;
+    ssemaps = NULL;
+    const int kk = topk < total ? topk : total;
+    sat_hit *hits = NULL;
+    int32_t *hit_maps = NULL;
+    if (topk > 0) {
+        /* best K per query: only K rows per query (and GPU) ever leave the GPUs */
+        hits = (sat_hit *)malloc(sizeof(sat_hit) * (size_t)kk * batch);
+        hit_maps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)kk * batch) : NULL;
+        if (!hits || (lsoln && !hit_maps)) { fprintf(stderr, "malloc failed\n"); exit(1); }
+    } else {
+        scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)total * batch);
+        ssemaps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)total * batch) : NULL;
+        if (!scores || (lsoln && !ssemaps)) { fprintf(stderr, "malloc failed\n"); exit(1); }
+    }
     uint8_t *qtabs = (uint8_t *)calloc((size_t)batch * SAT_MAXDIM * SAT_MAXDIM, 1);
     float *qdmats = (float *)calloc((size_t)batch * SAT_MAXDIM * SAT_MAXDIM, sizeof(float));
     uint8_t *qtypes = (uint8_t *)calloc((size_t)batch * SAT_MAXDIM, 1);
     int32_t *n1s = (int32_t *)malloc(sizeof(int32_t) * (size_t)batch);
-    if (!scores || (lsoln && !ssemaps) || !shard_scores || (lsoln && !shard_maps) || !qtabs || !qdmats || !qtypes || !n1s) {
+    if (!qtabs || !qdmats || !qtypes || !n1s) {
         fprintf(stderr, "malloc failed\n");
         exit(1);
     }
@@ -350,89 +350,36 @@ int main(int argc, char *argv[])
         }
         fprintf(stderr, "Executing simulated annealing tableaux match kernel on GPU for %d quer%s (from %s)...\n",
                 nqb, nqb == 1 ? "y" : "ies", sat_set_name(qsrc, qindex[q0]));
-        double t1 = now_ms();
-        for (int g = 0; g < ngpu; g++) {
-            if (sat_queries_set(ctx[g], nqb, n1s, qtabs, qdmats, SAT_MAXDIM, qtypes, (uint32_t)q0) != SAT_OK ||
-                sat_search_async(ctx[g], lorder, lsoln, maxstart) != SAT_OK) {
-                fprintf(stderr, "kernel launch failed: %s\n", sat_last_error());
-                exit_status = 1;
-                goto bye;
-            }
+        double ms = 0.0;
+        int rc = sat_multi_queries_set(multi, nqb, n1s, qtabs, qdmats, SAT_MAXDIM, qtypes, (uint32_t)q0);
+        if (rc == SAT_OK)
+            rc = topk > 0 ? sat_multi_search_topk(multi, lorder, lsoln, maxstart, kk, hits, hit_maps, &ms)
+                          : sat_multi_search(multi, lorder, lsoln, maxstart, scores, ssemaps, &ms);
+        if (rc < 0) {
+            fprintf(stderr, "kernel launch failed: %s\n", sat_last_error());
+            exit_status = 1;
+            goto bye;
         }
+        fprintf(stderr, "GPU execution time %f ms\n", ms);
+        fprintf(stderr, "%f million iterations/sec\n",
+                ((double)total * nqb * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
         if (topk > 0) {
-            /* best K per query: every GPU ranks its shard and computes the rows' statistics itself
-             * (sat_topk_hits); K rows per query and GPU come back - never the full score arrays - and the
-             * host merges the ngpu x K candidates */
-            const int kk = topk < total ? topk : total;
-            sat_hit *cand = (sat_hit *)malloc(sizeof(sat_hit) * (size_t)kk * nqb * ngpu);
-            int32_t *cand_maps = lsoln ? (int32_t *)malloc(sizeof(int32_t) * SAT_MAXDIM * (size_t)kk * nqb * ngpu) : NULL;
-            int *got = (int *)malloc(sizeof(int) * (size_t)ngpu);
-            if (!cand || (lsoln && !cand_maps) || !got) { fprintf(stderr, "malloc failed\n"); exit(1); }
-            for (int g = 0; g < ngpu; g++) {
-                got[g] = sat_topk_hits(ctx[g], kk, cand + (size_t)g * kk * nqb, lsoln ? cand_maps + (size_t)g * kk * nqb * SAT_MAXDIM : NULL);
-                if (got[g] < 0) {
-                    fprintf(stderr, "GPU %d top-k failed: %s\n", g, sat_last_error());
-                    exit_status = 1;
-                    goto bye;
-                }
-            }
-            double ms = now_ms() - t1;
-            fprintf(stderr, "GPU execution time %f ms\n", ms);
-            fprintf(stderr, "%f million iterations/sec\n",
-                    ((double)total * nqb * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
             for (int b = 0; b < nqb; b++) {
                 const int qs = qindex[q0 + b], n1 = n1s[b];
                 print_header(ltype, lorder, lsoln, sat_set_name(qsrc, qs), dbfile);
-                int head[MAX_GPUS];                      /* next unprinted row of each GPU's ranked list */
-                for (int g = 0; g < ngpu; g++) head[g] = 0;
-                for (int r = 0; r < kk; r++) {
-                    int bg = -1;
-                    for (int g = 0; g < ngpu; g++) {
-                        if (head[g] >= got[g]) continue;
-                        /* GPU g's rows: got[g] per query, from cand + g * kk * nqb */
-                        const sat_hit *h = cand + (size_t)g * kk * nqb + (size_t)b * got[g] + head[g];
-                        if (bg < 0) { bg = g; continue; }
-                        const sat_hit *hb = cand + (size_t)bg * kk * nqb + (size_t)b * got[bg] + head[bg];
-                        /* ties in database order: shards are contiguous, so the lower GPU wins */
-                        if (h->score > hb->score) bg = g;
-                    }
-                    if (bg < 0) break;
-                    const size_t row = (size_t)bg * kk * nqb + (size_t)b * got[bg] + head[bg];
-                    const sat_hit *h = cand + row;
-                    const int s2 = shard_begin[bg] + h->entry;
-                    printf("%-8s %d %g %g %g\n", sat_set_name(&db, s2), h->score, h->norm2, h->zscore, h->pvalue);
+                for (int r = 0; r < rc; r++) {
+                    const sat_hit *h = hits + (size_t)b * rc + r;
+                    printf("%-8s %d %g %g %g\n", sat_set_name(&db, h->entry), h->score, h->norm2, h->zscore, h->pvalue);
                     if (lsoln) {
-                        const int32_t *map = cand_maps + row * SAT_MAXDIM;
+                        const int32_t *map = hit_maps + ((size_t)b * rc + r) * SAT_MAXDIM;
                         for (int k2 = 0; k2 < n1; k2++)
                             if (map[k2] >= 0)
                                 printf("%3d %3d\n", k2 + 1, map[k2] + 1);
                     }
-                    head[bg]++;
                 }
             }
-            free(cand);
-            free(cand_maps);
-            free(got);
             continue;
         }
-        for (int g = 0; g < ngpu; g++) {
-            const int sb = shard_begin[g], sn = shard_begin[g + 1] - sb;
-            if (sat_results(ctx[g], lsoln, shard_scores, shard_maps) != SAT_OK) {
-                fprintf(stderr, "GPU %d search failed: %s\n", g, sat_last_error());
-                exit_status = 1;
-                goto bye;
-            }
-            for (int b = 0; b < nqb; b++) {          /* [query][shard entry] -> [query][db entry] */
-                memcpy(scores + (size_t)b * total + sb, shard_scores + (size_t)b * sn, sizeof(int32_t) * (size_t)sn);
-                if (lsoln)
-                    memcpy(ssemaps + ((size_t)b * total + sb) * SAT_MAXDIM, shard_maps + (size_t)b * sn * SAT_MAXDIM,
-                           sizeof(int32_t) * SAT_MAXDIM * (size_t)sn);
-            }
-        }
-        double ms = now_ms() - t1;
-        fprintf(stderr, "GPU execution time %f ms\n", ms);
-        fprintf(stderr, "%f million iterations/sec\n",
-                ((double)total * nqb * ((double)maxstart * SAT_MAXITER) / (ms / 1000)) / 1.0e6);
         for (int b = 0; b < nqb; b++) {
             const int qi = q0 + b, qs = qindex[qi], n1 = n1s[b];
             const int32_t *qscores = scores + (size_t)b * total;
@@ -463,13 +410,8 @@ int main(int argc, char *argv[])
             }
         }
 bye:
-    {
-        unsigned long long copied = 0;
-        for (int g = 0; g < ngpu; g++) copied += sat_stat_d2h_bytes(ctx[g]);
-        fprintf(stderr, "copied %llu bytes of results from the GPU(s)\n", copied);
-    }
-    for (int g = 0; g < ngpu; g++)
-        sat_ctx_destroy(ctx[g]);
+    fprintf(stderr, "copied %llu bytes of results from the GPU(s)\n", sat_multi_stat_d2h_bytes(multi));
+    sat_multi_destroy(multi);
     (void)cltype; (void)clorder; (void)clsoln;
     return exit_status;
 }

@@ -138,6 +138,7 @@ void free_db(sat_ctx *ctx)
     ctx->ssemaps_cap = 0;
     ctx->desc_dirty = true;
     ctx->n_entries = 0;
+    ctx->min_rows = 0;
     ctx->searched_nq = 0;
     ctx->h_orders.clear();
 }
@@ -206,7 +207,8 @@ const int kClassN1P[4] = { 16, 32, 64, 112 };
 int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
 {
     const size_t nq = ctx->queries.size();
-    const size_t need_scores = nq * (size_t)ctx->n_entries;
+    const size_t rows = (size_t)(ctx->n_entries > ctx->min_rows ? ctx->n_entries : ctx->min_rows);    // capacity only
+    const size_t need_scores = nq * rows;
     if (need_scores > ctx->scores_cap) {
         dev_free(ctx->d_scores);
         HIP_TRY(hipMalloc(&ctx->d_scores, need_scores * sizeof(int32_t)));
@@ -214,11 +216,13 @@ int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
         ctx->desc_dirty = true;
     }
     if (lsoln) {
-        size_t need = 0;
+        size_t need = 0, n1sum = 0;
         for (auto &q : ctx->queries) {
             q.ssemap_off = need;
             need += (size_t)ctx->n_entries * q.n1;
+            n1sum += (size_t)q.n1;
         }
+        if (rows * n1sum > need) need = rows * n1sum;
         if (need > ctx->ssemaps_cap) {
             dev_free(ctx->d_ssemaps);
             HIP_TRY(hipMalloc(&ctx->d_ssemaps, need));

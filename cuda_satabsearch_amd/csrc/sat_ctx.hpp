@@ -59,6 +59,10 @@ struct sat_ctx {
     size_t searched_nq = 0;                  // 0 = no search since the last upload / query change
     bool searched_lsoln = false;
 
+    // multi-GPU gather (sat_multi.hip): the result buffers are sized for at least this many rows per
+    // query, so that a fixed-size gather may read a shard padded to the largest shard
+    int min_rows = 0;
+
     // results: scores [nq][N]; ssemaps: query q's [N][n1_q] block at queries[q].ssemap_off
     int32_t *d_scores = nullptr;
     size_t scores_cap = 0;

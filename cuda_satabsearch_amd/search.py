@@ -223,3 +223,95 @@ class Searcher:
             "version": 3, "strides": None,
         }
         return torch.as_tensor(h, device=f"cuda:{self.device}")
+
+
+class MultiSearcher:
+    """One search over several GPUs from one host thread (sat_multi_* of the C ABI): cost-balanced
+    contiguous shards, the queries on every GPU, one gather of the shard rows to device 0."""
+
+    def __init__(self, ndev=0, devices=None, seed=DEFAULT_SEED):
+        self._lib = _native.device_lib()
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        self._m = self._lib.sat_multi_create(int(ndev), dev.ctypes.data if dev is not None else None, int(seed))
+        if not self._m:
+            raise SatError(self._lib.sat_last_error().decode())
+        self.ndev = int(self._lib.sat_multi_device_count(self._m))
+        self.n_entries = 0
+        self.n_queries = 0
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.sat_multi_destroy(self._m)
+            self._m = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise SatError(f"[{rc}] {self._lib.sat_last_error().decode()}")
+
+    @property
+    def gather_kind(self):
+        return self._lib.sat_multi_gather_kind(self._m).decode()
+
+    def upload(self, db: StructSet):
+        self._check(self._lib.sat_multi_db_upload_packed(self._m, len(db), db.orders.ctypes.data, db.cell_off.ctypes.data,
+                                                         db.tab.ctypes.data, db.dist.ctypes.data))
+        self.n_entries = len(db)
+
+    def shards(self):
+        begin = np.zeros(self.ndev + 1, np.int32)
+        self._check(self._lib.sat_multi_shards(self._m, begin.ctypes.data))
+        return begin
+
+    def set_queries(self, queries, first_query_ordinal=0):
+        nq = len(queries)
+        pitch = max(int(np.asarray(q[0]).shape[0]) for q in queries)
+        n1s = np.empty(nq, np.int32)
+        tabs = np.zeros((nq, pitch, pitch), np.uint8)
+        dmats = np.zeros((nq, pitch, pitch), np.float32)
+        types = np.zeros((nq, pitch), np.uint8)
+        for k, (t, d, ty) in enumerate(queries):
+            t = np.asarray(t, np.uint8)
+            d = np.asarray(d, np.float32)
+            n1 = t.shape[0]
+            n1s[k] = n1
+            tabs[k, :n1, :n1] = t[:, :n1]
+            dmats[k, :n1, :n1] = d[:, :n1]
+            types[k, :n1] = np.asarray(ty, np.uint8)[:n1] if ty is not None else np.diagonal(t)[:n1]
+        self._check(self._lib.sat_multi_queries_set(self._m, nq, n1s.ctypes.data, tabs.ctypes.data, dmats.ctypes.data,
+                                                    pitch, types.ctypes.data, int(first_query_ordinal)))
+        self.n_queries = nq
+
+    def search(self, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART):
+        """Returns (scores int32[nq, N], ssemaps int32[nq, N, 111] or None, wall_ms), database order."""
+        scores = np.empty((self.n_queries, self.n_entries), np.int32)
+        ssemaps = np.full((self.n_queries, self.n_entries, MAXDIM), -1, np.int32) if lsoln else None
+        ms = C.c_double(0.0)
+        self._check(self._lib.sat_multi_search(self._m, int(bool(lorder)), int(bool(lsoln)), int(maxstart), scores.ctypes.data,
+                                               ssemaps.ctypes.data if lsoln else None, C.byref(ms)))
+        return scores, ssemaps, ms.value
+
+    def search_topk(self, k, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART):
+        k = min(int(k), self.n_entries)
+        dt = np.dtype([("entry", np.int32), ("score", np.int32), ("norm2", np.float64), ("zscore", np.float64),
+                       ("pvalue", np.float64)], align=True)
+        hits = np.zeros((self.n_queries, k), dt)
+        maps = np.full((self.n_queries, k, MAXDIM), -1, np.int32) if lsoln else None
+        ms = C.c_double(0.0)
+        self._check(self._lib.sat_multi_search_topk(self._m, int(bool(lorder)), int(bool(lsoln)), int(maxstart), k,
+                                                    hits.ctypes.data, maps.ctypes.data if lsoln else None, C.byref(ms)))
+        return hits, maps, ms.value
+
+    def d2h_bytes(self):
+        return int(self._lib.sat_multi_stat_d2h_bytes(self._m))

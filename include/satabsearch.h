@@ -224,6 +224,43 @@ int sat_topk_hits(sat_ctx *ctx, int k, sat_hit *hits, int32_t *ssemaps);
 unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx);
 
 /*
+ * ---- one search over several GPUs of a node, driven from one host thread -------------------------
+ * The reference is single-GPU (cudaSaTabsearch.cu:790 "TODO allow multiple GPUs").  A sat_multi
+ * holds one context per GPU; the database is cut into contiguous shards of equal COST
+ * (csrc/host/sat_shard.h: real databases are size sorted and a 96-SSE entry costs four 32-SSE
+ * ones), each GPU holds its shard and the queries, a search is queued on all of them and ONE
+ * gather (RCCL ncclGather over xGMI; SAT_MULTI_GATHER=peer: hipMemcpyPeerAsync) brings the shard
+ * rows to device 0, from where one copy takes them to the host in database file order.  Results
+ * are identical for any number of GPUs (streams are keyed by the entry's ordinal in the database).
+ *
+ * sat_multi_create      ndev GPUs (<= 0: all visible; devices == NULL: 0 .. ndev-1)
+ * sat_multi_db_upload_packed   as sat_db_upload_packed for the WHOLE database (ordinals = file order)
+ * sat_multi_shards      begin[ndev + 1]: shard g holds entries begin[g] .. begin[g+1]-1
+ * sat_multi_queries_set as sat_queries_set, on every GPU
+ * sat_multi_search      as sat_search: scores [nq][n_entries] (and ssemaps) in database order;
+ *                       wall_ms = launch on all GPUs .. rows on the host
+ * sat_multi_search_topk the best k rows per query, each GPU ranking its own shard (sat_topk_hits) and
+ *                       the host merging ndev x k candidates; hits[q * k + r].entry is the index
+ *                       in the whole database; ssemaps as in sat_topk_hits
+ * sat_multi_gather_kind "rccl", "peer" or "none" (one GPU)
+ */
+typedef struct sat_multi sat_multi;
+sat_multi *sat_multi_create(int ndev, const int *devices, uint64_t seed);
+void sat_multi_destroy(sat_multi *m);
+int sat_multi_device_count(const sat_multi *m);
+const char *sat_multi_gather_kind(const sat_multi *m);
+int sat_multi_db_upload_packed(sat_multi *m, int n_entries, const int32_t *orders, const int64_t *cell_off,
+                               const uint8_t *tab_tri, const float *dist_tri);
+int sat_multi_shards(const sat_multi *m, int32_t *begin);
+int sat_multi_queries_set(sat_multi *m, int n_queries, const int32_t *n1s, const uint8_t *qtabs,
+                          const float *qdmats, int pitch, const uint8_t *qssetypes, uint32_t first_query_ordinal);
+int sat_multi_search(sat_multi *m, int lorder, int lsoln, int maxstart, int32_t *scores, int32_t *ssemaps,
+                     double *wall_ms);
+int sat_multi_search_topk(sat_multi *m, int lorder, int lsoln, int maxstart, int k, sat_hit *hits,
+                          int32_t *ssemaps, double *wall_ms);
+unsigned long long sat_multi_stat_d2h_bytes(const sat_multi *m);
+
+/*
  * Time `repeats` back-to-back searches with HIP events on the launch stream
  * (inputs resident, no copies inside the window).  Returns total milliseconds
  * in *total_ms and the dominant SA kernel's summed device time in *kernel_ms.

@@ -635,3 +635,34 @@ def test_philox_block_is_rocrands_block():
     bad = lib.sat_test_philox_vs_rocrand(n, seed.ctypes.data_as(ctypes.c_void_p), sub.ctypes.data_as(ctypes.c_void_p),
                                          block.ctypes.data_as(ctypes.c_void_p), ours, theirs)
     assert bad == 0, f"{bad} of {n} blocks differ from rocRAND's; first: ours {list(ours)} rocRAND {list(theirs)}"
+
+
+# ---------------------------------------------------------------- multi-GPU entry points (one GPU here)
+@pytest.mark.parametrize("gather", ["", "rccl", "peer"], ids=["direct", "rccl", "peer"])
+def test_multi_gpu_entry_points_on_one_device(monkeypatch, gather, golden_dir, small_db):
+    """sat_multi_*: cost-balanced shards, search on every GPU, ONE gather to device 0.  A box with one
+    GPU can only run one shard, but every code path is exercised: SAT_MULTI_GATHER=rccl sends the
+    shard through a one-rank RCCL communicator (ncclCommInitAll + ncclGather, the padded fixed-size
+    gather and the row re-ordering included), =peer through hipMemcpyPeerAsync; results must equal the
+    single-context search bit for bit, with solution maps and for the best-k rows.  (More than one
+    GPU: unmeasured on hardware, see DESIGN.md.)"""
+    if gather:
+        monkeypatch.setenv("SAT_MULTI_GATHER", gather)
+    qs = [load_query(golden_dir, "d2phlb1.input"), load_query(golden_dir, "multiquery.input", 0),
+          load_query(golden_dir, "multiquery.input", 2)]
+    with sat.Searcher(0) as s:
+        s.upload(small_db)
+        s.set_queries(qs, 3)
+        ref, refmaps, _ = s.search(True, True, 64)
+        refhits, refhitmaps = s.topk_hits(9, lsoln=True)
+    with sat.MultiSearcher(1) as m:
+        assert m.ndev == 1 and m.gather_kind == (gather or "none")
+        m.upload(small_db)
+        assert list(m.shards()) == [0, len(small_db)]
+        m.set_queries(qs, 3)
+        scores, maps, ms = m.search(True, True, 64)
+        assert np.array_equal(scores, ref) and np.array_equal(maps, refmaps)
+        hits, hitmaps, _ = m.search_topk(9, True, True, 64)
+        assert np.array_equal(hits, refhits) and np.array_equal(hitmaps, refhitmaps)
+        plain, none, _ = m.search(True, False, 64)
+        assert np.array_equal(plain, ref) and none is None

@@ -29,11 +29,13 @@ def _worker(rank, world, port, total, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = sat.sharding.shard_range(total, world, rank)
+    # size-sorted database: the cuts are placed by cumulative COST, so the shards differ in length
+    orders = sat.synth._orders(total, 6, 20, sat.synth.DB_SEED, True)
+    lo, hi = sat.sharding.shard_range(total, world, rank, orders)
     shard = sat.synth.make_db(hi - lo, 6, 20, first_index=lo, total=total)      # generated per rank
     q = sat.synth.planted_query(sat.synth.make_db(total, 6, 20), total - 3)
     scores, _, _ = oracle_lib.search(shard, *q, True, False, 32, db_ordinal=np.arange(lo, hi))
-    gathered = sat.sharding.gather_to_rank0(torch.from_numpy(scores), total, world, rank, dist)
+    gathered = sat.sharding.gather_to_rank0(torch.from_numpy(scores), total, world, rank, dist, orders=orders)
     if rank == 0:
         np.save(out_path, gathered.numpy())
     dist.barrier()
@@ -63,3 +65,37 @@ def test_shard_bounds_cover_everything():
             b = sat.sharding.shard_bounds(total, world)
             assert b[0] == 0 and b[-1] == total and all(b[i] <= b[i + 1] for i in range(world))
             assert max(b[i + 1] - b[i] for i in range(world)) - min(b[i + 1] - b[i] for i in range(world)) <= 1
+
+
+
+def test_cost_balanced_cuts_on_size_sorted_databases():
+    """real databases are size sorted, so the shards are cut by cumulative cost
+    (the measured per-order table of csrc/host/sat_shard.c), not by count: on the sorted C3 (orders
+    8..32) and C5 (8..111, 1 % above 96) order distributions the most expensive shard costs at most
+    1.1 x the cheapest for 2, 4 and 8 GPUs - where equal counts are off by up to 3 x."""
+    import cuda_satabsearch_amd as sat
+    n = 100_000
+    c3 = sat.synth._orders(n, 8, 32, sat.synth.DB_SEED, True)
+    c5 = sat.synth.orders_c5(n)
+    for name, orders in (("C3", c3), ("C5", c5)):
+        cost = sat.sharding.entry_cost(orders)
+        for world in (2, 4, 8):
+            b = sat.sharding.shard_bounds(n, world, orders)
+            assert b[0] == 0 and b[-1] == n and all(b[i] < b[i + 1] for i in range(world))
+            shard_cost = [cost[b[g]:b[g + 1]].sum() for g in range(world)]
+            assert max(shard_cost) / min(shard_cost) <= 1.1, (name, world, shard_cost)
+            eq = sat.sharding.shard_bounds(n, world)
+            eq_cost = [cost[eq[g]:eq[g + 1]].sum() for g in range(world)]
+            if name == "C5" and world == 8:
+                assert max(eq_cost) / min(eq_cost) > 3.0          # what equal counts would have given
+    # the cost model itself: 1.0 at 32 SSEs, monotone, the measured end points
+    assert sat.sharding.entry_cost([32])[0] == 1.0
+    c = sat.sharding.entry_cost(np.arange(1, 112))
+    assert (np.diff(c) >= 0).all() and 0.5 < c[0] < 0.6 and 5.5 < c[-1] < 5.8
+
+
+def test_cuts_degenerate_cases():
+    import cuda_satabsearch_amd as sat
+    assert sat.sharding.shard_bounds(3, 3, np.array([5, 100, 5])) == [0, 1, 2, 3]      # every shard non-empty
+    assert sat.sharding.shard_bounds(8, 2, np.array([111] + [4] * 7)) in ([0, 1, 8], [0, 2, 8])
+    assert sat.sharding.shard_bounds(5, 1, np.arange(1, 6)) == [0, 5]
