@@ -74,6 +74,7 @@ struct sat_multi {
     int n_entries = 0;
     int pad_rows = 0;                           // largest shard: every shard's rows are padded to it in the gather
     bool use_rccl = false;
+    bool force_gather = false;                  // SAT_MULTI_GATHER set: gather also with one GPU (tests)
     std::vector<ncclComm_t> comm;
     // gathered rows on device 0: [ndev][nq * pad_rows] scores, [ndev][pad_rows * sum(n1)] map bytes
     int32_t *d_all_scores = nullptr;
@@ -179,6 +180,7 @@ sat_multi *sat_multi_create(int ndev, const int *devices, uint64_t seed)
     const char *how = getenv("SAT_MULTI_GATHER");
     const bool want_peer = how && !strcmp(how, "peer");
     const bool force_rccl = how && !strcmp(how, "rccl");            // also with one GPU (tests)
+    m->force_gather = want_peer || force_rccl;
     if (!want_peer && (ndev > 1 || force_rccl) && g_rccl.load()) {
         m->comm.assign((size_t)ndev, nullptr);
         if (g_rccl.CommInitAll(m->comm.data(), ndev, m->devices.data()) == ncclSuccess) m->use_rccl = true;
@@ -223,7 +225,7 @@ int sat_multi_device_count(const sat_multi *m) { return m ? m->ndev : 0; }
 const char *sat_multi_gather_kind(const sat_multi *m)
 {
     if (!m) return "";
-    if (m->ndev == 1 && !m->use_rccl) return "none";
+    if (m->ndev == 1 && !m->force_gather) return "none";
     return m->use_rccl ? "rccl" : "peer";
 }
 
@@ -285,7 +287,7 @@ int sat_multi_search(sat_multi *m, int lorder, int lsoln, int maxstart, int32_t 
     }
     sat_ctx *root = m->ctx[0];
     const size_t nq = root->queries.size(), N = (size_t)m->n_entries, pad = (size_t)m->pad_rows;
-    if (m->ndev == 1 && !m->use_rccl) {
+    if (m->ndev == 1 && !m->force_gather) {
         int rc = sat_results(root, lsoln, scores, ssemaps);
         if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return rc;
