@@ -356,32 +356,64 @@ __host__ __device__ inline int map_words(int n1w)
     return lpi * wpl;
 }
 
-// LDS byte size of one workgroup
+// LDS carve of one workgroup, byte offsets from the dynamic-LDS base.  ONE function for the kernel
+// (its own entry's n2, its own query's padded map words) and for the host (the launch's largest):
+// the two cannot disagree, every offset keeps the alignment its users need (cells 16, query cells
+// 16, 64-bit reduction keys / the LSOLN leader key 8: a 64-bit LDS atomic on a 4-byte aligned
+// address faults), and the total grows with n2 and with the map words, so a workgroup sized for
+// the launch's largest member holds every member.
+struct LdsLayout {
+    uint32_t code;        // split cells only: the code bytes (distances start at 0)
+    uint32_t qdist;       // query cells staged in LDS (QLDS): float4 groups ...
+    uint32_t qcode;       // ... and their code dwords
+    uint32_t smap;        // chain maps, word-interleaved [word][chain], row stride chains + 1
+    uint32_t tmask;       // [4 types][4 words] db SSEs of a type
+    uint32_t qtypes;      // query SSE types
+    uint32_t red;         // 16 reduction keys + the LSOLN leader key (64-bit)
+    uint32_t items;       // per-wave item tables of the work compaction
+    uint32_t total;
+};
+__host__ __device__ inline LdsLayout lds_layout(bool split, int n2, int words, int n1p, int chains, int threads,
+                                                 bool q_in_lds, bool compact)
+{
+    LdsLayout L;
+    uint32_t dcells = (uint32_t)(n2 + 1) * (uint32_t)(n2 + 1);
+    uint32_t off;
+    if (split) {                                              // 4-byte distances + 1-byte codes (see DbRow)
+        dcells = (dcells + 3u) & ~3u;
+        L.code = dcells * 4u;
+        off = L.code + ((dcells + 15u) & ~15u);
+    } else {                                                  // 8-byte cells
+        dcells = (dcells + 1u) & ~1u;
+        L.code = 0u;
+        off = dcells * 8u;
+    }
+    L.qdist = off;                                            // 16-byte aligned in both layouts
+    if (q_in_lds) off += (uint32_t)words * (uint32_t)n1p * 16u;
+    L.qcode = off;
+    if (q_in_lds) off += (uint32_t)words * (uint32_t)n1p * 4u;
+    L.smap = off;
+    // an even word count keeps what follows 8-byte aligned
+    off += (((uint32_t)words * (uint32_t)(chains + 1) + 1u) & ~1u) * 4u;
+    L.tmask = off;
+    off += 16u * 4u;
+    L.qtypes = off;
+    off += ((uint32_t)n1p + 15u) & ~15u;
+    off = (off + 7u) & ~7u;
+    L.red = off;
+    off += 17u * 8u;
+    L.items = off;
+    if (compact) off += (uint32_t)((threads + 63) / 64) * 64u * 4u;      // compaction handles <= 64 rows per wave
+    L.total = off;
+    return L;
+}
+
+// LDS byte size of one workgroup (host side: the launch's largest query and entry)
 __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains, int threads, bool lsoln, bool q_in_lds,
                                              bool compact)
 {
-    size_t n1w = (size_t)((n1 + 3) >> 2);
-    size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
-    size_t bytes;
-    if (n2 > 32) {                                            // split cells (see DbRow), both arrays 16-byte multiples
-        dcells = (dcells + 3) & ~(size_t)3;
-        bytes = dcells * 4 + ((dcells + 15) & ~(size_t)15);
-    } else {
-        dcells = (dcells + 1) & ~(size_t)1;                   // keep 16-byte alignment
-        bytes = dcells * 8;
-    }
-    if (q_in_lds) bytes += (size_t)map_words((int)n1w) * (size_t)n1p * 20;   // float4 + code dword per (group, column)
-    // map words (padded), row stride chains + 1 (bank skew); an even word count keeps what follows
-    // 8-byte aligned (the 64-bit reduction keys and the LSOLN leader key, an LDS atomic)
-    bytes += (((size_t)map_words((int)n1w) * (chains + 1) + 1) & ~(size_t)1) * 4;
     (void)lsoln;                                              // the best maps live in global memory
-    bytes += 16 * 4;                                          // tmask[4][<=4]
-    bytes += ((size_t)n1p + 15) & ~(size_t)15;                // qtypes
-    bytes += 17 * 8;                                          // reduction scratch (<= 16 waves) + LSOLN leader key
-    if (compact) {
-        bytes += (size_t)((threads + 63) / 64) * 64 * 4;      // per-wave item table (compaction handles <= 64 rows)
-    }
-    return bytes;
+    return lds_layout(n2 > 32, n2, map_words((n1 + 3) >> 2), n1p, chains, threads, q_in_lds, compact).total;
 }
 
 #ifdef SAT_EXP_PERTURB
@@ -466,49 +498,46 @@ sat_sa_kernel(const SatKernelArgs a)
     const int NULLJ = n2;                       // the null db SSE
     const bool lsoln = FAST ? (OPT & 2) != 0 : a.lsoln != 0;
 
-    // ---- carve LDS (must match satk::lds_bytes)
-    // cell layout by the launch's size class, not by this entry's order (satk::lds_bytes sizes the
-    // workgroup for the largest entry of the launch with the same rule: n2max > 32 <=> M2W > 1)
-    constexpr bool SPLIT = M2W > 1;
-    size_t dcells = (size_t)(n2 + 1) * (n2 + 1);
-    dcells = SPLIT ? (dcells + 3) & ~(size_t)3 : (dcells + 1) & ~(size_t)1;
-    uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);                          // !SPLIT: 8-byte cells
-    float *distL = reinterpret_cast<float *>(lds_raw);                       // SPLIT: distances ...
-    uint8_t *codeL = reinterpret_cast<uint8_t *>(distL + dcells);           // ... and code bytes
-    unsigned char *after_cells = SPLIT ? codeL + ((dcells + 15) & ~(size_t)15) : reinterpret_cast<unsigned char *>(Dc + dcells);
-    auto db_row = [&](int j) -> DbRow<SPLIT> {
-        if constexpr (SPLIT) return DbRow<true>{ distL + __mul24(j, n2p), codeL + __mul24(j, n2p) };
-        else return DbRow<false>{ Dc + __mul24(j, n2p) };
-    };
     int cmp_lpi, cmp_wpl_q;
     compaction_shape(n1w, cmp_lpi, cmp_wpl_q);
     const int cmp_wpl = WPL > 0 ? WPL : cmp_wpl_q;           // the host launches WPL > 0 only where it matches
     const int cmp_words = cmp_lpi * cmp_wpl;                 // words n1w .. cmp_words - 1 stay "unmatched"
+    // ---- carve LDS: satk::lds_layout, the function the host sizes the workgroup with.  The cell layout
+    // goes by the launch's size class, not by this entry's order (n2max > 32 <=> M2W > 1).
+    constexpr bool SPLIT = M2W > 1;
+    const LdsLayout lay = lds_layout(SPLIT, n2, cmp_words, N1P, T, nthreads, QLDS, opt_compact);
+    uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);                          // !SPLIT: 8-byte cells
+    float *distL = reinterpret_cast<float *>(lds_raw);                       // SPLIT: distances ...
+    uint8_t *codeL = lds_raw + lay.code;                                     // ... and code bytes
+    auto db_row = [&](int j) -> DbRow<SPLIT> {
+        if constexpr (SPLIT) return DbRow<true>{ distL + __mul24(j, n2p), codeL + __mul24(j, n2p) };
+        else return DbRow<false>{ Dc + __mul24(j, n2p) };
+    };
     // query groups in LDS cover the padding words too (sentinel cells, like every group past n1w)
-    float4 *qdistL = reinterpret_cast<float4 *>(after_cells);
-    uint32_t *qcodeL = reinterpret_cast<uint32_t *>(qdistL + (QLDS ? (size_t)cmp_words * N1P : 0));
-    uint32_t *smap = qcodeL + (QLDS ? (size_t)cmp_words * N1P : 0);
+    float4 *qdistL = reinterpret_cast<float4 *>(lds_raw + lay.qdist);
+    uint32_t *qcodeL = reinterpret_cast<uint32_t *>(lds_raw + lay.qcode);
+    uint32_t *smap = reinterpret_cast<uint32_t *>(lds_raw + lay.smap);
     // map word w of chain c lives at w*TP + c with TP = T + 1: the odd stride puts the words of
     // one chain in different banks (the compacted loop reads them from several lanes at once) and
     // keeps word w of all chains contiguous for the static loops
     const int TP = T + 1;
-    uint32_t *tmask = smap + ((((size_t)cmp_words * TP) + 1) & ~(size_t)1);   // even: keeps `red` 8-byte aligned
+    uint32_t *tmask = reinterpret_cast<uint32_t *>(lds_raw + lay.tmask);
     // best maps: word w of chain c at w*T + c of this workgroup's slab (global memory)
     uint32_t *bmap = lsoln ? a.bmap_slabs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.bmap_slab_words : nullptr;
-    uint8_t *qtypes = reinterpret_cast<uint8_t *>(tmask + 16);
-    unsigned long long *red = reinterpret_cast<unsigned long long *>(qtypes + ((N1P + 15) & ~15));
+    uint8_t *qtypes = lds_raw + lay.qtypes;
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(lds_raw + lay.red);
     // explicit LDS address space: these two are written by some lanes and read by others of the
     // same wave between wavefront-scope fences, and must stay ds_* instructions
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     typedef __attribute__((address_space(3))) int32_t lds_i32_t;
-    const uint32_t items_off = (uint32_t)(reinterpret_cast<unsigned char *>(red + 17) - lds_raw);
+    const uint32_t items_off = lay.items;
     // LSOLN: key (score, restart) of the best proposal any chain of the workgroup has recorded so
     // far, same form as the final arg-max key.  A chain copies its map out only when its new best
     // beats this leader: the map that is finally output belongs to the chain with the largest key,
     // and that chain's last own-best proposal always beats every key recorded before it (a stale,
     // lower leader only causes a spare copy).  ~1150 copies per workgroup become ~20.
     typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
-    lds_u64_t *leader = (lds_u64_t *)(uintptr_t)(uint32_t)(reinterpret_cast<unsigned char *>(red + 16) - lds_raw);
+    lds_u64_t *leader = (lds_u64_t *)(uintptr_t)(lay.red + 16u * 8u);
     auto beats_leader = [&](int sc, int restart_) -> bool {
         const unsigned long long key = (((unsigned long long)(uint32_t)(sc + 0x40000000)) << 32) | (0xFFFFFFFFu - (uint32_t)restart_);
         if (key <= *leader) return false;

@@ -19,7 +19,8 @@
  * SAT_EXP_LDS_PAD = bytes (unused LDS added per workgroup: occupancy experiments),
  * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones),
  * SAT_EXP_STREAMS = 0 (queue the order buckets of a search one after the other instead of
- * concurrently on side streams).
+ * concurrently on side streams), SAT_EXP_UPLOAD_THREADS = n (host threads slicing the database
+ * copy, default 4), SAT_EXP_UPLOAD_TIMING = 1 (per-phase upload times on stderr).
  * There is no CPU fallback: without a usable HIP device sat_ctx_create() fails with
  * SAT_ENODEVICE.
  */
@@ -222,6 +223,15 @@ int sat_topk_hits(sat_ctx *ctx, int k, sat_hit *hits, int32_t *ssemaps);
 /* Bytes this context's result calls (sat_results, sat_search, sat_topk, sat_topk_hits) have copied
  * from the device to the host since it was created (diagnostics: the best-k path moves O(k) rows). */
 unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx);
+
+/*
+ * Diagnostics: the LDS carve of one workgroup of the SA kernel (csrc/sat_sa_kernel.hpp, lds_layout -
+ * the one function both the kernel and the launch sizing use), byte offsets out[0..8] = code bytes,
+ * query distances, query codes, chain maps, type masks, query types, reduction keys, item tables,
+ * total.  Lets tests assert alignment and monotonicity without a GPU.
+ */
+void sat_debug_lds_layout(int split, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
+                          uint32_t out[9]);
 
 /*
  * ---- one search over several GPUs of a node, driven from one host thread -------------------------

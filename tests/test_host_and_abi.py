@@ -153,3 +153,41 @@ def test_binary_image_round_trip(tmp_path):
     (tmp_path / "bad.satbin").write_bytes(bytes(bad))
     with pytest.raises(OSError):
         sat.StructSet.load_binary(tmp_path / "bad.satbin")
+
+
+def test_lds_carve_alignment_and_monotonicity():
+    """The SA kernel's LDS carve (one function for the kernel and for the launch sizing): the 64-bit
+    reduction keys / LSOLN leader key sit on 8-byte boundaries for EVERY shape (a 64-bit LDS atomic on
+    a 4-byte aligned address faulted in round 1 when an odd map-word count shifted them), cells and
+    query cells on 16, regions do not overlap, and the total grows with the entry order and the query
+    order - so a workgroup sized for the launch's largest member holds every member."""
+    lib = _native.device_lib()
+    out = (ctypes.c_uint32 * 9)()
+
+    def layout(split, n1, n1p, n2, chains, threads, qlds, compact):
+        lib.sat_debug_lds_layout(split, n1, n1p, n2, chains, threads, qlds, compact, out)
+        return list(out)
+
+    classes = [(16, range(1, 17)), (32, range(17, 33)), (64, range(33, 65)), (112, range(65, 112))]
+    for n1p, n1s in classes:
+        for n1 in list(n1s)[::3] + [n1s[-1]]:
+            for chains, lpc in ((64, 0), (128, 0), (192, 0), (256, 0), (64, 2), (128, 1)):
+                threads = chains << lpc
+                for qlds in (0, 1):
+                    for compact in (0, 1):
+                        prev_total = 0
+                        for n2 in list(range(1, 112, 5)) + [32, 33, 111]:
+                            split = int(n2 > 32)
+                            code, qdist, qcode, smap, tmask, qtypes, red, items, total = layout(split, n1, n1p, n2, chains, threads, qlds, compact)
+                            assert red % 8 == 0 and (red + 16 * 8) % 8 == 0, (n1, n2, chains)
+                            assert qdist % 16 == 0 and smap % 4 == 0 and tmask % 4 == 0 and items % 4 == 0
+                            assert code <= qdist <= qcode <= smap < tmask < qtypes < red < items <= total
+                            assert tmask - smap >= 4 * ((n1 + 3) // 4) * (chains + 1)
+                            assert items - red == 17 * 8 and qtypes - tmask == 64 and red - qtypes >= n1p
+                            assert total - items == (compact and ((threads + 63) // 64) * 256)
+                        # monotone in n2 within a cell layout, and in n1
+                        for split, orders in ((0, range(1, 33)), (1, range(33, 112))):
+                            totals = [layout(split, n1, n1p, n2, chains, threads, qlds, compact)[8] for n2 in orders]
+                            assert totals == sorted(totals)
+                        totals = [layout(0, k, n1p, 20, chains, threads, qlds, compact)[8] for k in n1s]
+                        assert totals == sorted(totals)
