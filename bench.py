@@ -211,11 +211,15 @@ def main():
         achieved = abytes / (kavg_ms * 1e-3) / 1e9
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (profiles/)
         traffic = None
+        traffic_source = None
         issue = None
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "bench_traffic.json")))
             if t.get("entries_per_launch") == n_local:
                 traffic = t["hbm_bytes_per_launch"]
+                # PMC counters need rocprofv3 passes of their own (the guide's recipe): they cannot be read
+                # inside this run, so the figure is the committed one of the same command and kernel
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scripts/profile_bench.sh)" % t.get("source")
                 if t.get("valu_wave_instr_per_launch"):
                     # what actually binds: VALU issue.  1024 SIMDs x one wave64 instr per 2 clk at 2.4 GHz
                     rate = t["valu_wave_instr_per_launch"] / (kavg_ms * 1e-3)
@@ -251,7 +255,9 @@ def main():
             "scorings_per_sec_incl_upload_single_query": total / (elapsed / args.steps + upload_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sat_sa_kernel<32,1,false,1,4>", "kernel_ms_avg": kavg_ms,
+                         "traffic_source": traffic_source,
+                         # the instantiation the library reports for the launches it just made
+                         "kernel": searcher.last_launch_info(), "kernel_ms_avg": kavg_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "nominal bound only: 2648 B per scoring against 12 800 dependent SA steps; "
                                  "the kernel is VALU/LDS-issue bound (DESIGN.md section 4)"},

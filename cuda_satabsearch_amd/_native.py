@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     "sat_db_upload_packed", "sat_db_upload_dense", "sat_db_size", "sat_query_set", "sat_search",
     "sat_search_async", "sat_device_scores", "sat_device_ssemaps", "sat_query_order", "sat_sync",
     "sat_search_timed", "sat_use_stream", "sat_use_own_stream", "sat_results", "sat_queries_set", "sat_query_count", "sat_topk",
-    "sat_topk_hits", "sat_stat_d2h_bytes", "sat_debug_lds_layout",
+    "sat_topk_hits", "sat_stat_d2h_bytes", "sat_debug_lds_layout", "sat_last_launch_info",
     "sat_multi_create", "sat_multi_destroy", "sat_multi_device_count", "sat_multi_gather_kind", "sat_multi_db_upload_packed",
     "sat_multi_shards", "sat_multi_queries_set", "sat_multi_search", "sat_multi_search_topk", "sat_multi_stat_d2h_bytes",
 )
@@ -87,6 +87,8 @@ def device_lib():
         lib.sat_topk_hits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.sat_stat_d2h_bytes.argtypes = [C.c_void_p]
         lib.sat_stat_d2h_bytes.restype = C.c_uint64
+        lib.sat_last_launch_info.argtypes = [C.c_void_p]
+        lib.sat_last_launch_info.restype = C.c_char_p
         lib.sat_debug_lds_layout.argtypes = [C.c_int] * 8 + [C.c_void_p]
         lib.sat_debug_lds_layout.restype = None
         lib.sat_multi_create.restype = C.c_void_p

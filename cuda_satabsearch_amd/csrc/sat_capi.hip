@@ -302,6 +302,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
 
     struct Planned {
         kernel_fn fn; SatKernelArgs args; int count, nqc, threads, n2max, max_entries; size_t lds, slab_words;
+        int n1p, m2w, qlds, opt, wpl;            // the instantiation's template arguments (sat_last_launch_info)
     };
     std::vector<Planned> plan;
     for (int c = 0; c < 4; c++) {
@@ -392,6 +393,14 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             pl.lds = lds;
             pl.n2max = n2max;
             pl.slab_words = lsoln ? (size_t)((n1max + 3) / 4) * chains : 0;
+            pl.n1p = n1p;
+            pl.m2w = m2w;
+            pl.qlds = qlds ? 1 : 0;
+            pl.opt = opt;
+            // the words-per-lane argument as pick_kernel resolves it (0 = read per query)
+            pl.wpl = (opt >= 0 && (opt & 1) && qlds == (n1p < 32)) ? ctx->class_wpl[c] : 0;
+            if (pl.wpl && !((pl.wpl == 4) || (pl.wpl == 3 && n1p <= 64) || (n1p == 16))) pl.wpl = 0;
+            if (opt < 0 || qlds != (n1p < 32)) pl.opt = -1;
             plan.push_back(pl);
         }
     }
@@ -459,6 +468,14 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
         }
     ctx->searched_nq = ctx->queries.size();
     ctx->searched_lsoln = lsoln != 0;
+    ctx->last_launch_info.clear();
+    for (size_t i = 0; i < plan.size(); i++) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "%ssat_sa_kernel<%d, %d, %s, %d, %d> grid %d x %d block %d lds %zu", i ? "; " : "", plan[i].n1p,
+                 plan[i].m2w, plan[i].qlds ? "true" : "false", plan[i].opt, plan[i].wpl, plan[i].count, plan[i].nqc,
+                 plan[i].threads, plan[i].lds);
+        ctx->last_launch_info += buf;
+    }
 #ifdef SAT_PHASE_TIMING
     {
         unsigned long long h[8];
@@ -891,6 +908,8 @@ void *sat_device_ssemaps(sat_ctx *ctx) { return ctx ? ctx->d_ssemaps : nullptr; 
 int sat_query_order(const sat_ctx *ctx) { return (ctx && !ctx->queries.empty()) ? ctx->queries[0].n1 : 0; }
 
 unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx) { return ctx ? ctx->d2h_bytes : 0ull; }
+
+const char *sat_last_launch_info(const sat_ctx *ctx) { return ctx ? ctx->last_launch_info.c_str() : ""; }
 
 void sat_debug_lds_layout(int split, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
                           uint32_t out[9])

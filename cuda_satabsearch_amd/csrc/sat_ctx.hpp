@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 #include <unordered_set>
 #include <vector>
 
@@ -87,6 +88,8 @@ struct sat_ctx {
 
     // bytes copied device -> host by this context's result calls (sat_stat_d2h_bytes)
     unsigned long long d2h_bytes = 0;
+    // kernel instantiations and launch geometry of the last search (sat_last_launch_info)
+    std::string last_launch_info;
 };
 
 

@@ -247,7 +247,13 @@ template <bool SPLIT>
 __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const DbRow<SPLIT> row,
                                           const uint32_t word, const uint32_t force, const int acc)
 {
+#if defined(SAT_ABLATE) && SAT_ABLATE == 1
+    // diagnostic build (scripts/exp/ablate_lds.sh): the four db cells from bank-conflict-free addresses
+    // (lane number instead of the map bytes) - wrong scores, only the LDS counters are read
+    const uint32_t l0 = (threadIdx.x + (word & 1u)) & 31u, l1 = l0, l2 = l0, l3 = l0;
+#else
     const uint32_t l0 = word & 0xFFu, l1 = (word >> 8) & 0xFFu, l2 = (word >> 16) & 0xFFu, l3 = word >> 24;
+#endif
     uint2 d0, d1, d2, d3;
     if constexpr (SPLIT) {
         d0 = uint2{ __float_as_uint(row.dist[l0]), row.code[l0] };
@@ -790,7 +796,11 @@ sat_sa_kernel(const SatKernelArgs a)
                     none = p < 0;
                     p = none ? 0 : p;
                 }
+#if defined(SAT_ABLATE) && SAT_ABLATE == 4
+                const int A = smap_b[map_byte_addr(p & 3)];                           // diagnostic: own-map byte reads from one word row
+#else
                 const int A = smap_b[map_byte_addr(p)];
+#endif
                 oldj = p == ssei ? A : NULLJ;
                 const uint32_t above = 0xFFFFFFFEu << (A & 31);          // bits A+1 .. 31
                 const uint32_t y = occ.w[0] & above;                     // occupied above A
@@ -894,7 +904,11 @@ sat_sa_kernel(const SatKernelArgs a)
                                 // words past the map (a lane's last one, when lpi does not divide n1w)
                                 // are padding: unmatched SSEs against the query's sentinel cells
                                 const int kwu = rkw + u * lpi;
+#if defined(SAT_ABLATE) && SAT_ABLATE == 2
+                                wd[u] = smap[kwu * TP + (lane_id & (T - 1))];      // diagnostic: conflict-free map reads
+#else
                                 wd[u] = smap[kwu * TP + owner];
+#endif
                                 const uint32_t qi = (uint32_t)(kwu * N1P + si);
                                 qd[u] = load_qdist(qi);
                                 qc[u] = load_qcode(qi);
@@ -911,8 +925,12 @@ sat_sa_kernel(const SatKernelArgs a)
                             v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
                             ok = ok && (rkw & 3) == 0;
                         }
+#if defined(SAT_ABLATE) && SAT_ABLATE == 3
+                        if (ok) items[lane_id & 63] += (uint32_t)v;                  // diagnostic: no atomics, one slot per lane
+#else
                         if (ok)
                             __hip_atomic_fetch_add((lds_i32_t *)(items + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
                     };
                     auto main_round = [&](int first) {
                         if constexpr (WPL > 0) one_round(std::integral_constant<int, WPL>{}, first, cmp_lpi, sub, kw, lane_ok);

@@ -197,6 +197,10 @@ class Searcher:
         """Bytes this context's result calls have copied device -> host so far."""
         return int(self._lib.sat_stat_d2h_bytes(self._ctx))
 
+    def last_launch_info(self):
+        """Kernel instantiations and launch geometry of the last search."""
+        return self._lib.sat_last_launch_info(self._ctx).decode()
+
     def sync(self):
         self._check(self._lib.sat_sync(self._ctx))
 

@@ -224,6 +224,10 @@ int sat_topk_hits(sat_ctx *ctx, int k, sat_hit *hits, int32_t *ssemaps);
  * from the device to the host since it was created (diagnostics: the best-k path moves O(k) rows). */
 unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx);
 
+/* Diagnostics: the kernel instantiations (template arguments as rocprofv3 prints them), grids, block
+ * sizes and LDS bytes of the launches of this context's last search, "; "-separated. */
+const char *sat_last_launch_info(const sat_ctx *ctx);
+
 /*
  * Diagnostics: the LDS carve of one workgroup of the SA kernel (csrc/sat_sa_kernel.hpp, lds_layout -
  * the one function both the kernel and the launch sizing use), byte offsets out[0..8] = code bytes,
