@@ -247,14 +247,18 @@ template <bool SPLIT>
 __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const DbRow<SPLIT> row,
                                           const uint32_t word, const uint32_t force, const int acc)
 {
-#if defined(SAT_ABLATE) && SAT_ABLATE == 1
-    // diagnostic build (scripts/exp/ablate_lds.sh): the four db cells from bank-conflict-free addresses
-    // (lane number instead of the map bytes) - wrong scores, only the LDS counters are read
-    const uint32_t l0 = (threadIdx.x + (word & 1u)) & 31u, l1 = l0, l2 = l0, l3 = l0;
-#else
     const uint32_t l0 = word & 0xFFu, l1 = (word >> 8) & 0xFFu, l2 = (word >> 16) & 0xFFu, l3 = word >> 24;
-#endif
     uint2 d0, d1, d2, d3;
+#if defined(SAT_DUP) && SAT_DUP == 1
+    // diagnostic build (scripts/exp/ablate_lds.sh): every db-cell gather is issued a second time (volatile,
+    // result dropped): scores unchanged, the LDS counters grow by exactly this access site's share
+    if constexpr (!SPLIT) {
+        typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_vu64;
+        const unsigned long long dup0 = *(lds_vu64)&row.cells[l0], dup1 = *(lds_vu64)&row.cells[l1],
+                                 dup2 = *(lds_vu64)&row.cells[l2], dup3 = *(lds_vu64)&row.cells[l3];
+        asm volatile("" : : "v"(dup0), "v"(dup1), "v"(dup2), "v"(dup3));
+    }
+#endif
     if constexpr (SPLIT) {
         d0 = uint2{ __float_as_uint(row.dist[l0]), row.code[l0] };
         d1 = uint2{ __float_as_uint(row.dist[l1]), row.code[l1] };
@@ -796,10 +800,9 @@ sat_sa_kernel(const SatKernelArgs a)
                     none = p < 0;
                     p = none ? 0 : p;
                 }
-#if defined(SAT_ABLATE) && SAT_ABLATE == 4
-                const int A = smap_b[map_byte_addr(p & 3)];                           // diagnostic: own-map byte reads from one word row
-#else
                 const int A = smap_b[map_byte_addr(p)];
+#if defined(SAT_DUP) && SAT_DUP == 4
+                (void)*(const volatile __attribute__((address_space(3))) uint8_t *)&smap_b[map_byte_addr(p)];   // diagnostic: own-map byte read twice
 #endif
                 oldj = p == ssei ? A : NULLJ;
                 const uint32_t above = 0xFFFFFFFEu << (A & 31);          // bits A+1 .. 31
@@ -904,10 +907,9 @@ sat_sa_kernel(const SatKernelArgs a)
                                 // words past the map (a lane's last one, when lpi does not divide n1w)
                                 // are padding: unmatched SSEs against the query's sentinel cells
                                 const int kwu = rkw + u * lpi;
-#if defined(SAT_ABLATE) && SAT_ABLATE == 2
-                                wd[u] = smap[kwu * TP + (lane_id & (T - 1))];      // diagnostic: conflict-free map reads
-#else
                                 wd[u] = smap[kwu * TP + owner];
+#if defined(SAT_DUP) && SAT_DUP == 2
+                                (void)*(const volatile __attribute__((address_space(3))) uint32_t *)&smap[kwu * TP + owner];   // diagnostic: map word read twice
 #endif
                                 const uint32_t qi = (uint32_t)(kwu * N1P + si);
                                 qd[u] = load_qdist(qi);
@@ -925,11 +927,11 @@ sat_sa_kernel(const SatKernelArgs a)
                             v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
                             ok = ok && (rkw & 3) == 0;
                         }
-#if defined(SAT_ABLATE) && SAT_ABLATE == 3
-                        if (ok) items[lane_id & 63] += (uint32_t)v;                  // diagnostic: no atomics, one slot per lane
-#else
                         if (ok)
                             __hip_atomic_fetch_add((lds_i32_t *)(items + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#if defined(SAT_DUP) && SAT_DUP == 3
+                        if (ok)                                                          // diagnostic: a second atomic (adds 0)
+                            __hip_atomic_fetch_add((lds_i32_t *)(items + idx), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #endif
                     };
                     auto main_round = [&](int first) {

@@ -1,16 +1,17 @@
 #!/bin/bash
 # scripts/exp/ablate_lds.sh - which LDS access site makes the bank conflicts of the bench kernel?
-# Builds diagnostic variants of the device library (SAT_ABLATE = 1: db-cell gathers from conflict-free
-# addresses, 2: chain-map words of the rounds conflict free, 3: item accumulators without atomics,
-# 4: own-map byte reads of the proposal from one word row; results are WRONG in these builds, only
-# the counters are read) and, on the GPU box, collects SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE /
-# SQ_INSTS_LDS and the kernel time of the bench workload for each.
+# Builds diagnostic variants of the device library in which ONE access site is issued twice (SAT_DUP =
+# 1: the db-cell gathers of the pair evaluation, 2: the chain-map words of the rounds, 3: the item
+# accumulator atomics, 4: the own-map byte read of the proposal; volatile duplicates, results
+# unchanged) and, on the GPU box, collects SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS and
+# the kernel time of the bench workload for each: a site's share is the growth over the base build.
+# (Removing or redirecting an access instead changes the SA trajectories and with them the work.)
 #   build (container):  scripts/exp/ablate_lds.sh build
 #   run (GPU box):      scripts/exp/ablate_lds.sh run   -> gpurun_out/ablate_lds.txt
 set -uo pipefail
 repo=$(cd "$(dirname "$0")/../.." && pwd)
 if [ "${1:-}" = build ]; then
-  for k in 1 2 3 4; do bash $repo/scripts/exp/variant_lib.sh abl$k -DSAT_ABLATE=$k & done; wait
+  for k in 1 2 3 4; do bash $repo/scripts/exp/variant_lib.sh abl$k -DSAT_DUP=$k & done; wait
   exit 0
 fi
 out=$repo/gpurun_out/ablate_lds.txt; : > $out

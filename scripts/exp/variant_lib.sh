@@ -7,7 +7,9 @@
 set -e
 repo=$(cd "$(dirname "$0")/../.." && pwd)
 name=$1; shift
+# same inputs as cuda_satabsearch_amd/build.py build_device (the host-C objects come from a normal build)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared "$@" \
   -I $repo/include -I $repo/cuda_satabsearch_amd/csrc -o $repo/cuda_satabsearch_amd/libsat_$name.so \
-  $repo/cuda_satabsearch_amd/csrc/sat_capi.hip $repo/cuda_satabsearch_amd/csrc/sat_topk.hip
+  $repo/cuda_satabsearch_amd/csrc/sat_capi.hip $repo/cuda_satabsearch_amd/csrc/sat_topk.hip $repo/cuda_satabsearch_amd/csrc/sat_multi.hip \
+  -Wl,$repo/cuda_satabsearch_amd/sat_gumbel.o -Wl,$repo/cuda_satabsearch_amd/sat_shard.o -lm -ldl
 echo "built cuda_satabsearch_amd/libsat_$name.so"
