@@ -54,3 +54,9 @@ ls -la "$here/expected"
 cp "$here/inputs/readme_1ubq.input" "$work/"
 "$repo/oracle/_ref/ref_oracle" -c -r128 < readme_1ubq.input > "$here/expected/readme_1ubq.r128.out" 2>/dev/null
 sed -n 43,49p /root/reference/README_example_usage.txt | sed 's/^    //' > "$here/expected/readme_1ubq.printed_head.txt"
+
+# -q mode (SIDs on stdin; the second one is upper case and longer than 7 characters: cut + case-insensitive
+# lookup, cudaSaTabsearch.cu:657, 752): the reference's parser, kernel and statistics under ref_driver's
+# replay of main's -q branch
+printf 'd1kcul1\nD1NLDL1xyz\nd1lfwa2\n' > "$here/inputs/qmode_sids.txt"
+"$repo/oracle/_ref/ref_oracle" -c -r16 -q tableauxdistmatrixdb.small.ascii < "$here/inputs/qmode_sids.txt" > "$here/expected/qmode_small.r16.out" 2>/dev/null

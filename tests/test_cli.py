@@ -30,6 +30,14 @@ def test_host_mode_is_byte_identical_to_reference(golden_dir, name):
     assert p.stdout == open(os.path.join(EXPECTED, name + ".r128.out"), "rb").read()
 
 
+def test_host_mode_query_list_matches_reference_build(golden_dir):
+    """The product's `-c -q` against the reference-built golden (tests/golden/make_golden.sh)."""
+    sids = open(os.path.join(golden_dir, "qmode_sids.txt"), "rb").read()
+    p = run(CLI, golden_dir, ["-c", "-r", "16", "-q", "tableauxdistmatrixdb.small.ascii"], stdin_bytes=sids)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    assert p.stdout == open(os.path.join(EXPECTED, "qmode_small.r16.out"), "rb").read()
+
+
 def test_host_mode_query_list(golden_dir):
     sids = b"d1kcul1\nD1NLDL1\n"
     a = run(CLI, golden_dir, ["-c", "-r", "16", "-q", "tableauxdistmatrixdb.small.ascii"], stdin_bytes=sids)

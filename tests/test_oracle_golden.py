@@ -61,6 +61,22 @@ def test_oracle_reproduces_recorded_2013_run(golden_dir):
         assert out == f.read()
 
 
+def test_q_mode_matches_reference_build(golden_dir):
+    """`-q dbfile` with SIDs on stdin: the golden stdout comes from the reference's own parser, kernel
+    and statistics under oracle/ref_driver.cpp's replay of main's -q branch (SID cut to 7 characters,
+    case-insensitive lookup, the query copied out of the database arrays off-diagonal cell by cell,
+    cudaSaTabsearch.cu:631-664, 746-780, 356-400)."""
+    with open(os.path.join(golden_dir, "qmode_sids.txt"), "rb") as f:
+        sids = f.read()
+    assert b"D1NLDL1xyz" in sids
+    p = subprocess.run([CLI, "-c", "-r", "16", "-q", "tableauxdistmatrixdb.small.ascii"], input=sids, cwd=golden_dir,
+                       capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    with open(os.path.join(EXPECTED, "qmode_small.r16.out"), "rb") as f:
+        gold = f.read()
+    assert p.stdout == gold and gold.count(b"# QUERY ID") == 3 and b"# QUERY ID = d1nldl1" in gold
+
+
 def test_q_mode_equals_inline_query(golden_dir):
     """-q takes SIDs of db members; the same structure given inline must give the same
     rows (options are fixed T T F in -q mode, cudaSaTabsearch.cu:633-635)."""
