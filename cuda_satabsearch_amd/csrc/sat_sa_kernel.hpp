@@ -508,8 +508,12 @@ sat_sa_kernel(const SatKernelArgs a)
     const int NULLJ = n2;                       // the null db SSE
     const bool lsoln = FAST ? (OPT & 2) != 0 : a.lsoln != 0;
 
-    int cmp_lpi, cmp_wpl_q;
-    compaction_shape(n1w, cmp_lpi, cmp_wpl_q);
+    int cmp_lpi_q, cmp_wpl_q;
+    compaction_shape(n1w, cmp_lpi_q, cmp_wpl_q);
+    // lanes per listed row = ceil(n1w / 4): a compile-time fact in the two small query classes (1 for up to
+    // 16 SSEs, 2 for 17..32), which turns the word strides of the rounds into instruction offsets
+    constexpr int LPI_CT = N1P == 16 ? 1 : (N1P == 32 ? 2 : 0);
+    const int cmp_lpi = LPI_CT ? LPI_CT : cmp_lpi_q;
     const int cmp_wpl = WPL > 0 ? WPL : cmp_wpl_q;           // the host launches WPL > 0 only where it matches
     const int cmp_words = cmp_lpi * cmp_wpl;                 // words n1w .. cmp_words - 1 stay "unmatched"
     // ---- carve LDS: satk::lds_layout, the function the host sizes the workgroup with.  The cell layout
