@@ -291,12 +291,13 @@ __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, co
 }
 
 // ---------------------------------------------------------------- random streams
-// Block `block` of the chain's Philox stream through the rocRAND device API:
+// Block `block` of the chain's Philox stream, written out by hand (NOT a call into rocRAND), laid out as rocRAND's:
 // key = seed_q, counter = (block, 0, subsequence lo, subsequence hi).
 __device__ __forceinline__ uint4 philox_block(uint64_t seed_q, uint64_t subsequence, uint32_t block)
 {
     // Philox4x32-10 written out (same words as rocrand_init(seed_q, subsequence, 4 * block) +
-    // rocrand4, which tests/ check through the oracle): in every use here the block and the low
+    // rocrand4 - checked on the device against rocRAND's own device API by
+    // tests/test_gpu_parity.py::test_philox_block_is_rocrands_block): in every use here the block and the low
     // subsequence word are wave-uniform, so rounds 1-3 are left to the compiler (it keeps the
     // uniform half on the scalar unit); from round 4 on all four words are per lane and the two
     // three-way XORs of a round are one v_bitop3_b32 each.
