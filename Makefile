@@ -13,7 +13,7 @@ HOST     = $(CSRC)/host
 all: $(PKG)/libsathost.so $(PKG)/libsatabsearch.so $(PKG)/bin/satabsearch
 
 $(PKG)/libsathost.so: $(HOST)/sat_parse.c $(HOST)/sat_gumbel.c $(HOST)/sat_shard.c $(HOST)/sat_parse.h $(HOST)/sat_gumbel.h $(HOST)/sat_shard.h
-	$(CC) -O2 -fPIC -shared -Wall -Wextra -I$(HOST) -o $@ $(HOST)/sat_parse.c $(HOST)/sat_gumbel.c $(HOST)/sat_shard.c -lm
+	$(CC) -O2 -fPIC -shared -Wall -Wextra -I$(HOST) -o $@ $(HOST)/sat_parse.c $(HOST)/sat_gumbel.c $(HOST)/sat_shard.c -lm -lpthread
 
 $(PKG)/sat_shard.o: $(HOST)/sat_shard.c $(HOST)/sat_shard.h
 	$(CC) -O2 -fPIC -ffp-contract=off -Wall -Wextra -I$(HOST) -c -o $@ $(HOST)/sat_shard.c

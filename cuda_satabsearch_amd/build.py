@@ -42,7 +42,7 @@ def build_host(force=False):
     srcs = [os.path.join(HOST, f) for f in ("sat_parse.c", "sat_gumbel.c", "sat_shard.c")]
     deps = srcs + [os.path.join(HOST, f) for f in ("sat_parse.h", "sat_gumbel.h", "sat_shard.h")]
     if force or _stale(out, deps):
-        _run([CC, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", HOST, "-o", out] + srcs + ["-lm"])
+        _run([CC, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", HOST, "-o", out] + srcs + ["-lm", "-lpthread"])
     return out
 
 

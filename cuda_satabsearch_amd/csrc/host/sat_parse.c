@@ -19,6 +19,7 @@
  */
 #include <ctype.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -73,6 +74,33 @@ static int grow_cells(sat_struct_set *set, int64_t extra)
     if (!d) return -1;
     set->dist = d;
     set->cells_cap = ncap;
+    return 0;
+}
+
+/* room for at least `count` entries and `cells` cells in total */
+static int reserve(sat_struct_set *set, int count, int64_t cells)
+{
+    if (count > set->capacity) {
+        int *o = (int *)realloc(set->order, (size_t)count * sizeof(int));
+        if (!o) return -1;
+        set->order = o;
+        char *nm = (char *)realloc(set->name, (size_t)count * (SAT_LABELSIZE + 1));
+        if (!nm) return -1;
+        set->name = nm;
+        int64_t *co = (int64_t *)realloc(set->cell_off, (size_t)count * sizeof(int64_t));
+        if (!co) return -1;
+        set->cell_off = co;
+        set->capacity = count;
+    }
+    if (cells > set->cells_cap) {
+        uint8_t *t = (uint8_t *)realloc(set->tab, (size_t)cells);
+        if (!t) return -1;
+        set->tab = t;
+        float *d = (float *)realloc(set->dist, (size_t)cells * sizeof(float));
+        if (!d) return -1;
+        set->dist = d;
+        set->cells_cap = cells;
+    }
     return 0;
 }
 
@@ -283,7 +311,7 @@ float sat_distance_cell(const char *text)
     return distance_at(text);
 }
 
-int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, const char *what)
+static int read_structures_span(const char *text, size_t len, sat_struct_set *set, const char *what, size_t *consumed)
 {
     char buf[SAT_MAX_LINE_LEN];
     uint8_t *tri_tab = (uint8_t *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2);
@@ -339,7 +367,129 @@ int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, c
     set->skipped += skipped;
     free(tri_tab);
     free(tri_dist);
+    if (consumed) *consumed = (size_t)(c.p - text);
     return added;
+}
+
+int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, const char *what)
+{
+    return read_structures_span(text, len, set, what, NULL);
+}
+
+/* ---- parallel parse of a memory image: the file is cut at record headers, every piece is parsed by
+ * its own thread into its own set, the sets are concatenated.  A piece must end exactly where the next
+ * begins (a record that claims more rows than it has would run into its neighbour): if any does not,
+ * the whole image is parsed again sequentially, which is what defines the result. */
+
+/* does a record header ("name order": two blank-separated tokens, the second all digits) start at p? */
+static int looks_like_header(const char *p, const char *end)
+{
+    const char *q = p;
+    while (q < end && (*q == ' ' || *q == '\t')) q++;
+    int n = 0;
+    while (q < end && !is_space(*q) && n <= SAT_LABELSIZE) { q++; n++; }
+    if (n == 0 || n > SAT_LABELSIZE) return 0;
+    if (q >= end || (*q != ' ' && *q != '\t')) return 0;
+    while (q < end && (*q == ' ' || *q == '\t')) q++;
+    int digits = 0;
+    while (q < end && isdigit((unsigned char)*q)) { q++; digits++; }
+    if (digits == 0 || digits > 4) return 0;
+    while (q < end && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+    return q >= end || *q == '\n';
+}
+
+typedef struct parse_job {
+    const char *text;
+    size_t len;
+    const char *what;
+    sat_struct_set set;
+    size_t consumed;
+    int added;
+} parse_job;
+
+static void *parse_job_run(void *arg)
+{
+    parse_job *j = (parse_job *)arg;
+    j->added = read_structures_span(j->text, j->len, &j->set, j->what, &j->consumed);
+    return NULL;
+}
+
+int sat_read_structures_mem_mt(const char *text, size_t len, sat_struct_set *set, const char *what, int nthreads)
+{
+    const size_t min_piece = (size_t)1 << 20;
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads > 1 && len / (size_t)nthreads < min_piece) nthreads = (int)(len / min_piece);
+    if (nthreads < 2) return sat_read_structures_mem(text, len, set, what);
+
+    const int count_before = set->count;
+    parse_job *jobs = (parse_job *)calloc((size_t)nthreads, sizeof(parse_job));
+    pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    size_t *start = (size_t *)calloc((size_t)nthreads + 1, sizeof(size_t));
+    if (!jobs || !tid || !start) { free(jobs); free(tid); free(start); return -1; }
+    const char *end = text + len;
+    int pieces = 0;
+    start[pieces++] = 0;
+    for (int t = 1; t < nthreads; t++) {
+        const char *p = text + len * (size_t)t / (size_t)nthreads;
+        if (p <= text + start[pieces - 1]) continue;
+        /* the next line start at or after p whose line looks like a record header */
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        p = nl ? nl + 1 : end;
+        while (p < end && !looks_like_header(p, end)) {
+            nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            p = nl ? nl + 1 : end;
+        }
+        if (p < end && (size_t)(p - text) > start[pieces - 1]) start[pieces++] = (size_t)(p - text);
+    }
+    start[pieces] = len;
+    int ok = 1, launched = 0;
+    for (int t = 0; t < pieces; t++) {
+        jobs[t].text = text + start[t];
+        jobs[t].len = start[t + 1] - start[t];
+        jobs[t].what = what;
+        sat_set_init(&jobs[t].set);
+        if (pthread_create(&tid[t], NULL, parse_job_run, &jobs[t]) != 0) { ok = 0; break; }
+        launched++;
+    }
+    for (int t = 0; t < launched; t++) pthread_join(tid[t], NULL);
+    for (int t = 0; ok && t < pieces; t++) {
+        if (jobs[t].added < 0) ok = 0;
+        /* the piece must have been consumed to its end, blanks aside */
+        const char *q = jobs[t].text + jobs[t].consumed, *pe = jobs[t].text + jobs[t].len;
+        while (q < pe && is_space(*q)) q++;
+        if (q != pe) ok = 0;
+    }
+    int total = -1;
+    if (ok) {
+        /* concatenate: one reservation, then whole-array copies per piece (offsets rebased) */
+        int add_count = 0;
+        int64_t add_cells = 0;
+        for (int t = 0; t < pieces; t++) { add_count += jobs[t].set.count; add_cells += jobs[t].set.cells; }
+        if (reserve(set, set->count + add_count, set->cells + add_cells) != 0) ok = 0;
+        for (int t = 0; ok && t < pieces; t++) {
+            const sat_struct_set *ps = &jobs[t].set;
+            if (ps->count > 0) {
+                memcpy(set->order + set->count, ps->order, (size_t)ps->count * sizeof(int));
+                memcpy(set->name + (size_t)set->count * (SAT_LABELSIZE + 1), ps->name, (size_t)ps->count * (SAT_LABELSIZE + 1));
+                for (int k = 0; k < ps->count; k++) set->cell_off[set->count + k] = ps->cell_off[k] + set->cells;
+                memcpy(set->tab + set->cells, ps->tab, (size_t)ps->cells);
+                memcpy(set->dist + set->cells, ps->dist, (size_t)ps->cells * sizeof(float));
+                set->count += ps->count;
+                set->cells += ps->cells;
+            }
+            set->skipped += ps->skipped;
+        }
+        total = ok ? add_count : -1;
+    }
+    for (int t = 0; t < pieces; t++) sat_set_free(&jobs[t].set);
+    free(jobs); free(tid); free(start);
+    if (!ok) {
+        /* a piece did not end at its cut (or a thread could not be started): the sequential parse decides.
+         * Nothing has been appended to `set` unless the merge itself failed - an allocation failure. */
+        if (set->count != count_before) return -1;
+        return sat_read_structures_mem(text, len, set, what);
+    }
+    return total;
 }
 
 int sat_read_structures_file(const char *path, sat_struct_set *set, const char *what)
@@ -352,8 +502,13 @@ int sat_read_structures_file(const char *path, sat_struct_set *set, const char *
     void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (map == MAP_FAILED) return -1;
-    (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
-    int n = sat_read_structures_mem((const char *)map, (size_t)st.st_size, set, what);
+    (void)madvise(map, (size_t)st.st_size, MADV_WILLNEED);
+    /* big files are parsed by several threads (SAT_PARSE_THREADS overrides the count, 1 = sequential) */
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    int nthreads = cores > 16 ? 16 : (cores < 1 ? 1 : (int)cores);
+    const char *ov = getenv("SAT_PARSE_THREADS");
+    if (ov && atoi(ov) > 0) nthreads = atoi(ov);
+    int n = sat_read_structures_mem_mt((const char *)map, (size_t)st.st_size, set, what, nthreads);
     munmap(map, (size_t)st.st_size);
     return n;
 }

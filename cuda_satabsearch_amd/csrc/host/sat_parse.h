@@ -71,11 +71,20 @@ int sat_read_structures(FILE *fp, sat_struct_set *set, const char *what);
  */
 int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, const char *what);
 
+/*
+ * The same on `nthreads` threads: the image is cut at record headers near the equal-size marks, the
+ * pieces are parsed concurrently and concatenated in file order.  A piece that does not end exactly at
+ * its cut (a record claiming more rows than it has) makes the whole image go through the sequential
+ * reader again, whose result is the definition.  Per-record warnings may interleave on stderr.
+ */
+int sat_read_structures_mem_mt(const char *text, size_t len, sat_struct_set *set, const char *what, int nthreads);
+
 /* One distance cell exactly as the memory-image reader parses it (exposed for the tests that
  * compare the fast path with strtof over its whole domain). */
 float sat_distance_cell(const char *text);
 
-/* mmap `path` and parse it with sat_read_structures_mem; -1 if the file cannot be mapped. */
+/* mmap `path` and parse it with sat_read_structures_mem_mt on up to 16 threads (SAT_PARSE_THREADS
+ * overrides the count; files under 2 MB are parsed sequentially); -1 if the file cannot be mapped. */
 int sat_read_structures_file(const char *path, sat_struct_set *set, const char *what);
 
 /*

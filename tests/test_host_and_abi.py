@@ -191,3 +191,35 @@ def test_lds_carve_alignment_and_monotonicity():
                             assert totals == sorted(totals)
                         totals = [layout(0, k, n1p, 20, chains, threads, qlds, compact)[8] for k in n1s]
                         assert totals == sorted(totals)
+
+
+def test_parallel_reader_equals_sequential(tmp_path, monkeypatch):
+    """The mmap reader cuts big files at record headers and parses the pieces on several threads; the
+    result must be the sequential reader's, entry for entry - also when a piece does not end at its cut
+    (here: a stray one-token line in the middle, at which the reference grammar stops reading), where the
+    sequential parse is run again and decides."""
+    db = sat.synth.make_db(12_000, 4, 40, sort=False, seed=13)
+    path = tmp_path / "db.ascii"
+    db.write_ascii(path)
+    assert os.path.getsize(path) > 8 << 20
+    monkeypatch.setenv("SAT_PARSE_THREADS", "1")
+    seq = sat.StructSet.read(path)
+    assert len(seq) == len(db) and np.array_equal(seq.tab, db.tab) and np.array_equal(seq.dist, db.dist)
+    for threads in ("2", "3", "7", "16"):
+        monkeypatch.setenv("SAT_PARSE_THREADS", threads)
+        par = sat.StructSet.read(path)
+        assert par.names == seq.names and np.array_equal(par.orders, seq.orders)
+        assert np.array_equal(par.cell_off, seq.cell_off)
+        assert np.array_equal(par.tab, seq.tab) and np.array_equal(par.dist, seq.dist)
+    # a stray line after the 7000th record: reading stops there (fscanf("%8s %d") fails)
+    text = open(path).read()
+    records = text.split("\n\n")
+    broken = "\n\n".join(records[:7000]) + "\n\nstray\n\n" + "\n\n".join(records[7000:])
+    bad = tmp_path / "stray.ascii"
+    open(bad, "w").write(broken)
+    monkeypatch.setenv("SAT_PARSE_THREADS", "1")
+    seq = sat.StructSet.read(bad)
+    assert len(seq) == 7000
+    monkeypatch.setenv("SAT_PARSE_THREADS", "8")
+    par = sat.StructSet.read(bad)
+    assert par.names == seq.names and np.array_equal(par.tab, seq.tab) and np.array_equal(par.dist, seq.dist)
