@@ -334,15 +334,8 @@ __device__ __forceinline__ float to_uniform(uint32_t v)
 {
     return draw32(v) * 2.3283064365386963e-10f;
 }
-// (int)((u - EPS) * n) evaluated in double, as K.cu:1042 and K.cu:710 do, from w = 2^32 * u:
-// w * 2^-32 is exact in double, so the fused multiply-add rounds once, where u - EPS rounds.
-__device__ __forceinline__ int scaled_index(float w, double n)
-{
-    return (int)(__builtin_fma((double)w, 2.3283064365386963e-10, -SAT_K_EPS) * n);
-}
-
-// The same index from a 16-bit draw v: u = (v + 1) * 2^-16 in (0, 1] (exact in float), index =
-// (int)((u - EPS) * n) evaluated in double as above.  For n <= 111 that equals the integer
+// Index draw from a 16-bit value v: u = (v + 1) * 2^-16 in (0, 1] (exact in float), index =
+// (int)((u - EPS) * n) evaluated in double, as K.cu:1042 and K.cu:710 do.  For n <= 111 that equals the integer
 // ((v + 1) * n - 1) >> 16: when (v + 1) * n is a multiple of 2^16 the EPS term drops the index by
 // one, otherwise the fractional part is at least 2^-16 > EPS * n and nothing changes
 // (tests/test_oracle_units.py checks all 65536 x 111 cases against the double expression).
@@ -500,9 +493,6 @@ sat_sa_kernel(const SatKernelArgs a)
     const int e = a.entry_list[blockIdx.x];
     const SatQuery Q = a.queries[blockIdx.y];
     const int n1 = Q.n1;
-    // (double)n1 kept in scalar registers: as a plain value the compiler converts it again every step
-    const double n1d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint((double)n1)),
-                                        __builtin_amdgcn_readfirstlane(__double2loint((double)n1)));
     const int n2 = a.orders[e];
     const int n2p = n2 + 1;
     const int n1w = (n1 + 3) >> 2;

@@ -32,6 +32,12 @@ elif name == "n96":
     db, queries = sat.synth.make_db(20_000, 96), [w.config3_query()]
 elif name == "n64":
     db, queries = sat.synth.make_db(40_000, 64), [w.config3_query()]
+elif name == "q200":
+    # the reference paper's workload shape (scripts/mkquery200tab.sh, *querylist*.sh): 200 database members
+    # as a query list against a ~15 000-entry size-sorted database, one batch
+    db = sat.synth.make_db(15_000, 4, 40, sort=True)
+    pick = np.random.default_rng(5).choice(len(db), 200, replace=False)
+    queries = [(*db.dense(int(s)), db.ssetypes(int(s))) for s in pick]
 elif name == "q101":
     db, queries = sat.synth.make_db(20_000, 8, 96, sort=True), [w.config4_query()[1:]]
 else:
