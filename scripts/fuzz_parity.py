@@ -11,7 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t0 = time.time()
 cases = 0
-with sat.Searcher(0, seed=77) as s:
+if True:
     while time.time() - t0 < budget:
         n = int(rng.integers(3, 60))
         lo = int(rng.integers(1, 40)); hi = int(rng.integers(lo, min(111, lo + int(rng.integers(1, 80))) + 1))
@@ -33,9 +33,18 @@ with sat.Searcher(0, seed=77) as s:
         for k, v in (("SAT_EXP_LPC", rng.choice(["", "0", "1", "2"])), ("SAT_EXP_COMPACT", rng.choice(["", "0", "1"]))):
             if v: os.environ[k] = str(v)
             else: os.environ.pop(k, None)
-        s.upload(db)
-        s.set_query(*q, qord)
-        sc, mp, _ = s.search(lorder, lsoln, r)
+        # the launch-heuristic overrides are read when a context is created: one context per case
+        with sat.Searcher(0, seed=77) as s:
+            s.upload(db)
+            s.set_query(*q, qord)
+            sc, mp, _ = s.search(lorder, lsoln, r)
+            if rng.random() < 0.3:                       # the best-k rows of the same search
+                k = int(rng.integers(1, n + 3))
+                hits = s.topk_hits(k)
+                order = np.lexsort((np.arange(n), -sc.astype(np.int64)))[:min(k, n)]
+                if not (np.array_equal(hits[0]["entry"], order) and np.array_equal(hits[0]["score"], sc[order])):
+                    print("TOPK MISMATCH", dict(n=n, k=k))
+                    sys.exit(1)
         osc, omp, _ = oracle_lib.search(db, *q, lorder, lsoln, r, seed=77, query_ordinal=qord)
         ok = np.array_equal(sc, osc) and (not lsoln or np.array_equal(mp, omp))
         cases += 1
