@@ -20,7 +20,8 @@
  * sequential drand48 stream, byte-identical to the reference's -c.  It is never a
  * fallback: without -c a missing GPU is an error.
  *
- * Extensions: -g N (GPUs to use, default all visible), -s SEED (Philox seed, default 1234),
+ * Extensions: -g N (GPUs to use, default all visible), -G 0,2,3 (which GPUs; a GPU named twice
+ * holds two shards), -s SEED (Philox seed, default 1234),
  * -k K (print only the K best rows per query, ranked on the GPU by raw score, ties in
  * database order - the `sort -k 2,2nr | head` users run on the reference's output),
  * -b (keep a binary image `dbfile.satbin` beside the database and load it instead of
@@ -49,12 +50,13 @@ static double now_ms(void)
 
 static void usage(const char *prog)
 {
-    fprintf(stderr, "Usage: %s [-c] [-q dbfile] [-r restarts] [-g gpus] [-s seed]\n", prog);
+    fprintf(stderr, "Usage: %s [-c] [-q dbfile] [-r restarts] [-g gpus] [-G gpu,gpu,...] [-s seed] [-k K] [-b]\n", prog);
     fprintf(stderr, "  -c : run on host CPU not GPU card\n");
     fprintf(stderr, "  -q dbfile : database is read from dbfile, list of query\n"
                     "              ids is read from stdin\n");
     fprintf(stderr, "  -r restarts : number of restarts. Default %d\n", 128);
     fprintf(stderr, "  -g gpus : number of GPUs to shard the database over. Default all\n");
+    fprintf(stderr, "  -G list : the GPUs to use, e.g. 0,2,3 (a GPU named twice holds two shards)\n");
     fprintf(stderr, "  -s seed : seed of the GPU random streams. Default %d\n", SAT_DEFAULT_SEED);
     fprintf(stderr, "  -k K : print only the K best rows per query (GPU mode)\n");
     fprintf(stderr, "  -b : cache the parsed database as dbfile.satbin\n");
@@ -92,12 +94,17 @@ int main(int argc, char *argv[])
     char cltype = 'F', clorder = 'F', clsoln = 'F';
     int c;
 
-    while ((c = getopt(argc, argv, "cq:r:g:s:bk:")) != -1) {
+    int dev_list[64], ndev_list = 0;
+    while ((c = getopt(argc, argv, "cq:r:g:G:s:bk:")) != -1) {
         switch (c) {
         case 'c': use_gpu = 0; break;
         case 'q': querydbmode = 1; strncpy(dbfile, optarg, sizeof(dbfile) - 1); break;
         case 'r': maxstart = atoi(optarg); break;
         case 'g': want_gpus = atoi(optarg); break;
+        case 'G':
+            for (char *tok = strtok(optarg, ","); tok && ndev_list < 64; tok = strtok(NULL, ","))
+                dev_list[ndev_list++] = atoi(tok);
+            break;
         case 's': seed = strtoull(optarg, NULL, 0); break;
         case 'b': bincache = 1; break;
         case 'k': topk = atoi(optarg); break;
@@ -267,13 +274,14 @@ int main(int argc, char *argv[])
     fprintf(stderr, "found %d HIP devices\n", ndev);
     int ngpu = want_gpus > 0 ? want_gpus : ndev;
     if (ngpu > ndev) ngpu = ndev;
+    if (ndev_list > 0) ngpu = ndev_list;
     if (ngpu > total) ngpu = total;
 
     /* One multi-GPU context: the database is cut into contiguous shards of equal COST (entries of a
      * size-sorted database differ several-fold in cost, sat_shard.h), every GPU holds its shard, a
      * search is queued on all of them and one gather (RCCL over xGMI) brings the rows to device 0. */
     t0 = now_ms();
-    sat_multi *multi = sat_multi_create(ngpu, NULL, seed);
+    sat_multi *multi = sat_multi_create(ngpu, ndev_list > 0 ? dev_list : NULL, seed);
     if (!multi) {
         fprintf(stderr, "sat_multi_create(%d) failed: %s\n", ngpu, sat_last_error());
         exit(1);

@@ -157,7 +157,11 @@ sat_multi *sat_multi_create(int ndev, const int *devices, uint64_t seed)
 {
     const int visible = sat_device_count();
     if (ndev <= 0) ndev = visible;
-    if (visible <= 0 || ndev > visible) {
+    // an explicit device list may name a device more than once (several shards on one GPU: how the
+    // multi-shard path is exercised on a one-GPU box; RCCL refuses duplicates, peer copies do not)
+    bool listed_ok = devices != nullptr;
+    for (int g = 0; listed_ok && g < ndev; g++) listed_ok = devices[g] >= 0 && devices[g] < visible;
+    if (visible <= 0 || (devices ? !listed_ok : ndev > visible)) {
         sat_fail(SAT_ENODEVICE, "%d GPUs asked for, %d visible (this library has no CPU path)", ndev, visible);
         return nullptr;
     }
@@ -181,7 +185,10 @@ sat_multi *sat_multi_create(int ndev, const int *devices, uint64_t seed)
     const bool want_peer = how && !strcmp(how, "peer");
     const bool force_rccl = how && !strcmp(how, "rccl");            // also with one GPU (tests)
     m->force_gather = want_peer || force_rccl;
-    if (!want_peer && (ndev > 1 || force_rccl) && g_rccl.load()) {
+    bool duplicates = false;
+    for (int g = 0; g < ndev; g++)
+        for (int h = 0; h < g; h++) duplicates = duplicates || m->devices[(size_t)g] == m->devices[(size_t)h];
+    if (!want_peer && !duplicates && (ndev > 1 || force_rccl) && g_rccl.load()) {
         m->comm.assign((size_t)ndev, nullptr);
         if (g_rccl.CommInitAll(m->comm.data(), ndev, m->devices.data()) == ncclSuccess) m->use_rccl = true;
         else m->comm.clear();

@@ -247,7 +247,8 @@ void sat_debug_lds_layout(int split, int n1, int n1p, int n2, int chains, int th
  * rows to device 0, from where one copy takes them to the host in database file order.  Results
  * are identical for any number of GPUs (streams are keyed by the entry's ordinal in the database).
  *
- * sat_multi_create      ndev GPUs (<= 0: all visible; devices == NULL: 0 .. ndev-1)
+ * sat_multi_create      ndev GPUs (<= 0: all visible; devices == NULL: 0 .. ndev-1; a list may name a GPU more
+ *                       than once - several shards on one GPU, gathered by peer copies)
  * sat_multi_db_upload_packed   as sat_db_upload_packed for the WHOLE database (ordinals = file order)
  * sat_multi_shards      begin[ndev + 1]: shard g holds entries begin[g] .. begin[g+1]-1
  * sat_multi_queries_set as sat_queries_set, on every GPU

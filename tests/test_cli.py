@@ -152,3 +152,15 @@ def test_gpu_mode_topk_never_downloads_the_score_arrays(tmp_path):
         rows = sorted(enumerate(b["rows"]), key=lambda t: (-int(t[1].split()[1]), t[0]))[:10]
         expect += b["head"] + [r for _, r in rows]
     assert top.stdout.decode().splitlines() == expect
+
+
+@pytest.mark.gpu
+def test_gpu_mode_output_does_not_depend_on_the_shards(golden_dir):
+    """-G 0,0,0: three cost-balanced shards of the database (all on GPU 0 here) give byte for byte the
+    stdout of the one-shard run, solution maps included, and the same best-k rows."""
+    for name, extra in (("d2phlb1_TTT", []), ("multiquery", []), ("multiquery", ["-k", "5"])):
+        one = run(CLI, golden_dir, ["-r", "64", *extra], stdin_path=name + ".input")
+        three = run(CLI, golden_dir, ["-r", "64", "-G", "0,0,0", *extra], stdin_path=name + ".input")
+        assert one.returncode == 0 and three.returncode == 0, three.stderr.decode()[-300:]
+        assert one.stdout == three.stdout
+        assert b"to 3 GPU(s)" in three.stderr and b"gather: peer" in three.stderr

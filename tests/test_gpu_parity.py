@@ -666,3 +666,34 @@ def test_multi_gpu_entry_points_on_one_device(monkeypatch, gather, golden_dir, s
         assert np.array_equal(hits, refhits) and np.array_equal(hitmaps, refhitmaps)
         plain, none, _ = m.search(True, False, 64)
         assert np.array_equal(plain, ref) and none is None
+
+
+@pytest.mark.parametrize("nshards", [2, 3, 5])
+def test_multi_shard_path_with_several_contexts_on_one_gpu(nshards, golden_dir):
+    """The multi-GPU code path with REAL shards on a one-GPU box: an explicit device list that names GPU
+    0 several times gives one context per shard (peer-copy gather: RCCL refuses duplicate devices).
+    Cost-balanced cuts of a size-sorted database, padded fixed-size gather, rows put back in database
+    order, solution maps, and the merge of the per-shard best-k rows: all equal to the one-context search."""
+    db = sat.synth.make_db(700, 4, 70, sort=True, seed=31)
+    qs = [sat.synth.planted_query(db, 650, keep=0.6), load_query(golden_dir, "d2phlb1.input"), sat.synth.make_query(8)]
+    with sat.Searcher(0) as s:
+        s.upload(db)
+        s.set_queries(qs, 2)
+        ref, refmaps, _ = s.search(True, True, 64)
+        refhits, refhitmaps = s.topk_hits(20, lsoln=True)
+    with sat.MultiSearcher(nshards, devices=[0] * nshards) as m:
+        assert m.ndev == nshards and m.gather_kind == "peer"
+        m.upload(db)
+        b = m.shards()
+        assert b[0] == 0 and b[-1] == len(db) and (np.diff(b) > 0).all()
+        cost = sat.sharding.entry_cost(db.orders)
+        shard_cost = [cost[b[g]:b[g + 1]].sum() for g in range(nshards)]
+        assert max(shard_cost) / min(shard_cost) < 1.25              # 700 entries: coarse, but far from the 5x of equal counts
+        assert len(set(np.diff(b).tolist())) > 1                      # unequal shard lengths: the gather pads
+        m.set_queries(qs, 2)
+        scores, maps, _ = m.search(True, True, 64)
+        assert np.array_equal(scores, ref) and np.array_equal(maps, refmaps)
+        hits, hitmaps, _ = m.search_topk(20, True, True, 64)
+        assert np.array_equal(hits, refhits) and np.array_equal(hitmaps, refhitmaps)
+        plain, _, _ = m.search(True, False, 64)
+        assert np.array_equal(plain, ref)
