@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "sat_ctx.hpp"
@@ -248,15 +250,31 @@ int sat_multi_db_upload_packed(sat_multi *m, int n_entries, const int32_t *order
     m->pad_rows = 0;
     std::vector<int64_t> ordinal((size_t)n_entries);
     for (int e = 0; e < n_entries; e++) ordinal[(size_t)e] = e;
-    for (int g = 0; g < m->ndev; g++) {
+    // every GPU has its own link to the host: the shards go up concurrently, one host thread per GPU
+    std::vector<int> rcs((size_t)m->ndev, SAT_OK);
+    std::vector<std::string> errs((size_t)m->ndev);
+    auto upload_shard = [&](int g) {
         const int b = m->begin[(size_t)g], n = m->begin[(size_t)g + 1] - b;
-        if (n > m->pad_rows) m->pad_rows = n;
         // a shard is a window of the packed arrays: rebase its cell offsets to the window
         std::vector<int64_t> off((size_t)n);
         for (int e = 0; e < n; e++) off[(size_t)e] = cell_off[b + e] - cell_off[b];
-        int rc = sat_db_upload_packed(m->ctx[(size_t)g], n, orders + b, off.data(), tab_tri + cell_off[b], dist_tri + cell_off[b],
-                                      ordinal.data() + b);
-        if (rc != SAT_OK) return rc;
+        rcs[(size_t)g] = sat_db_upload_packed(m->ctx[(size_t)g], n, orders + b, off.data(), tab_tri + cell_off[b],
+                                              dist_tri + cell_off[b], ordinal.data() + b);
+        if (rcs[(size_t)g] != SAT_OK) errs[(size_t)g] = sat_last_error();      // the message is per thread
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int g = 1; g < m->ndev; g++) pool.emplace_back(upload_shard, g);
+        upload_shard(0);
+        for (auto &th : pool) th.join();
+    }
+    for (int g = 0; g < m->ndev; g++) {
+        if (rcs[(size_t)g] != SAT_OK) {
+            // entry numbers in the message are relative to the shard: say which
+            return sat_fail(rcs[(size_t)g], "shard %d (entries from %d): %s", g, m->begin[(size_t)g], errs[(size_t)g].c_str());
+        }
+        const int n = m->begin[(size_t)g + 1] - m->begin[(size_t)g];
+        if (n > m->pad_rows) m->pad_rows = n;
     }
     for (int g = 0; g < m->ndev; g++) m->ctx[(size_t)g]->min_rows = m->pad_rows;     // result buffers hold a padded shard
     return SAT_OK;
