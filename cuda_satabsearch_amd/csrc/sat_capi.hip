@@ -175,11 +175,28 @@ template <int N1P, int OPT> kernel_fn pick_wpl(int m2w, int wpl)
     }
 }
 
+// several lanes per chain with the options as compile-time facts: only for the largest entries (M2W = 4),
+// words per lane read per query
+template <int N1P, bool QLDS> kernel_fn pick_lpc(int opt)
+{
+    switch (opt) {
+    case 4: return sat_sa_kernel<N1P, 4, QLDS, 4, 0>;
+    case 5: return sat_sa_kernel<N1P, 4, QLDS, 5, 0>;
+    case 6: return sat_sa_kernel<N1P, 4, QLDS, 6, 0>;
+    case 7: return sat_sa_kernel<N1P, 4, QLDS, 7, 0>;
+    case 8: return sat_sa_kernel<N1P, 4, QLDS, 8, 0>;
+    case 9: return sat_sa_kernel<N1P, 4, QLDS, 9, 0>;
+    case 10: return sat_sa_kernel<N1P, 4, QLDS, 10, 0>;
+    default: return sat_sa_kernel<N1P, 4, QLDS, 11, 0>;
+    }
+}
+
 template <int N1P> kernel_fn pick_n1p(int m2w, bool qlds, int opt, int wpl)
 {
     constexpr bool kQ = N1P < 32;
     kernel_fn fn = nullptr;
-    if (opt >= 0 && qlds == kQ) {
+    if (opt >= 4 && qlds == kQ && m2w == 4) return pick_lpc<N1P, kQ>(opt);
+    if (opt >= 0 && opt < 4 && qlds == kQ) {
         switch (opt) {
         case 0: fn = pick_wpl<N1P, 0>(m2w, wpl); break;
         case 1: fn = pick_wpl<N1P, 1>(m2w, wpl); break;
@@ -376,8 +393,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             a.lpc_shift = lpc_shift;
             a.compact = compact ? 1 : 0;
             // option-specialised instantiation when the layout is the default one for these options
-            const bool special = lpc_shift == 0 && compact == (lorder != 0) && !ctx->tune.general;
-            const int opt = special ? (lorder ? 1 : 0) | (lsoln ? 2 : 0) : -1;
+            const bool special = (lpc_shift == 0 || m2w == 4) && compact == (lorder != 0) && !ctx->tune.general;
+            const int opt = special ? (lorder ? 1 : 0) | (lsoln ? 2 : 0) | (lpc_shift << 2) : -1;
             kernel_fn fn = pick_kernel(n1p, m2w, qlds, opt, ctx->class_wpl[c]);
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
             if (ctx->lds_attr_done.insert(reinterpret_cast<const void *>(fn)).second)
@@ -398,7 +415,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             pl.qlds = qlds ? 1 : 0;
             pl.opt = opt;
             // the words-per-lane argument as pick_kernel resolves it (0 = read per query)
-            pl.wpl = (opt >= 0 && (opt & 1) && qlds == (n1p < 32)) ? ctx->class_wpl[c] : 0;
+            pl.wpl = (opt >= 0 && opt < 4 && (opt & 1) && qlds == (n1p < 32)) ? ctx->class_wpl[c] : 0;
             if (pl.wpl && !((pl.wpl == 4) || (pl.wpl == 3 && n1p <= 64) || (n1p == 16))) pl.wpl = 0;
             if (opt < 0 || qlds != (n1p < 32)) pl.opt = -1;
             plan.push_back(pl);

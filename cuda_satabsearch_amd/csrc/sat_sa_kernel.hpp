@@ -465,14 +465,16 @@ __device__ __forceinline__ void perturb(uint32_t (&d)[4])
 
 // N1P: pitch of the query cell matrix (>= 4*ceil(n1/4)); M2W: 32-bit words of a db-side
 // bit set (n2 <= 32*M2W); QLDS: query cells staged in LDS (else read through L1/L2).
-// OPT: -1 = every option is read from the arguments (the general instantiation: several lanes
+// OPT: >= 0: bit 0 LORDER, bit 1 LSOLN, bits 2-3 log2(lanes per chain) as compile-time facts (lanes per
+// chain above one only instantiated for the largest entries, M2W = 4, where that layout is the default).
+// -1 = every option is read from the arguments (the general instantiation: forced layouts, several lanes
 // per chain, forced layouts); otherwise the options are compile-time facts - bit 0 LORDER, bit 1
 // LSOLN, one lane per chain, work compaction exactly when LORDER - and their tests leave the SA
 // step loop (the general kernel spills ~90 SGPRs and is ~9 % slower on the bench shape).
 // WPL: map words per lane in the compacted rounds (satk::compaction_shape) when every query of
 // the launch has the same; 0 = read it from the query (a four-way switch per step).
 template <int N1P, int M2W, bool QLDS, int OPT, int WPL>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(OPT < 0 ? 4 : 6)))
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu((OPT < 0 || OPT >= 4) ? 4 : 6)))
 sat_sa_kernel(const SatKernelArgs a)
 {
     using namespace satk;
@@ -483,7 +485,7 @@ sat_sa_kernel(const SatKernelArgs a)
     const int nthreads = blockDim.x;
     // chain = restart slot of this lane; `part` of `lpc` adjacent lanes share one chain
     constexpr bool FAST = OPT >= 0;
-    const int lpc_shift = FAST ? 0 : a.lpc_shift;
+    const int lpc_shift = FAST ? (OPT >> 2) : a.lpc_shift;      // OPT bits 2-3: log2(lanes per chain), 0..2
     const bool opt_lorder = FAST ? (OPT & 1) != 0 : a.lorder != 0;
     const bool opt_compact = FAST ? (OPT & 1) != 0 : a.compact != 0;
     const int lpc = 1 << lpc_shift;
