@@ -168,3 +168,30 @@ def test_mixed_size_database_throughput_and_stream_overlap(monkeypatch):
             assert np.array_equal(sc, ref)
     print(f"\nmixed-size db (orders 8..32, sorted) x 32-SSE query, r=128: {rates['1']:,.0f} scorings/s with the buckets "
           f"on side streams, {rates['0']:,.0f} queued on one stream")
+
+
+def test_query_list_workload_of_the_paper():
+    """The reference's published workload shape (scripts/mkquery200tab.sh, *querylist*.sh): 200 database
+    members as ONE query batch against a ~15 000-entry size-sorted database, r = 128: every query's own
+    entry is (or ties) its best hit, a sample of (query, entry) pairs equals the oracle bit for bit, and the
+    best-10 rows per query come back without the 12 MB of score arrays."""
+    db = sat.synth.make_db(15_000, 4, 40, sort=True)
+    pick = np.random.default_rng(5).choice(len(db), 200, replace=False)
+    queries = [(*db.dense(int(s)), db.ssetypes(int(s))) for s in pick]
+    with sat.Searcher(0) as s:
+        s.upload(db)
+        s.set_queries(queries, 0)
+        scores, _, ms = s.search(True, False, 128)
+        before = s.d2h_bytes()
+        hits = s.topk_hits(10)
+        assert s.d2h_bytes() - before == 200 * 10 * 32
+    assert scores.shape == (200, len(db))
+    for qi, src in enumerate(pick):
+        assert scores[qi][src] == scores[qi].max()
+        order = np.lexsort((np.arange(len(db)), -scores[qi].astype(np.int64)))[:10]
+        assert np.array_equal(hits[qi]["entry"], order)
+    sample = workloads.sample_entries(len(db), 24, seed=8)
+    for qi in (0, 57, 199):
+        osc, _, _ = oracle_lib.search(db, *queries[qi], True, False, 128, entries=sample, query_ordinal=qi)
+        assert np.array_equal(scores[qi][sample], osc)
+    print(f"\n200 queries x {len(db)} entries, r=128, one batch: {ms:.1f} ms -> {200 * len(db) / ms * 1e3:,.0f} scorings/s")
