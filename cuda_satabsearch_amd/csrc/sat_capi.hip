@@ -672,7 +672,9 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
         if (timing) { const double t = now_ms(); fprintf(stderr, "upload: %-18s %7.3f ms\n", what, t - t_mark); t_mark = t; }
     };
 
-    // bucket lists, file order kept inside a bucket
+    // bucket lists; inside a bucket the LARGEST entries first (file order among equals): workgroups are
+    // dispatched in list order and a larger entry runs longer, so the launch ends on its cheapest
+    // workgroups instead of its dearest (real databases are sorted ascending)
     std::vector<int32_t> lists;
     lists.reserve(n_entries);
     for (int b = 0; b < kNumBuckets; b++) {
@@ -684,6 +686,8 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
                 lists.push_back(e);
                 if (orders[e] > ctx->bucket_n2max[b]) ctx->bucket_n2max[b] = orders[e];
             }
+        std::stable_sort(lists.begin() + ctx->bucket_begin[b], lists.end(),
+                         [&](int32_t x, int32_t y) { return orders[x] > orders[y]; });
     }
     ctx->bucket_begin[kNumBuckets] = (int)lists.size();
 
