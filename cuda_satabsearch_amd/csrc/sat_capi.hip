@@ -287,6 +287,33 @@ int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
     return SAT_OK;
 }
 
+// Entries per workgroup.  A CU hands out its LDS in 128 granules of 1280 bytes (measured,
+// scripts/exp/lds_probe.hip: 128-thread workgroups drop from 12 to 11 to 10 per CU at 12 800 and 14 080
+// bytes, 384-thread ones from 4 to 3 at 40 960), so a workgroup of one entry wastes up to a granule plus
+// what is left over at the end of the CU.  k entries side by side round up once: the bench entry's
+// 13 320 bytes fit 11 times alone (11 granules each) and 6 x 2 times in pairs (21 granules a pair).
+// Picks the smallest k with the most resident entries, the register file's wave limit included.  Only
+// workgroups of a multiple of 4 waves and at most 512 threads are considered: measured on the bench,
+// 6-wave workgroups do not spread evenly over the 4 SIMDs (8.5 M scorings/s against 10.6 M), and 12-wave
+// ones lose to their own start-up and drain phases what the extra residency gains (10.4 M).
+int pick_epw(kernel_fn fn, int threads, size_t lds_stride)
+{
+    int best = 1, best_entries = 0;
+    for (int k = 1; k * threads <= 512 && (size_t)k * lds_stride <= kLdsLimit; k++) {
+        if (k > 1 && (k * threads / 64) % 4 != 0) continue;
+        int by_regs = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, reinterpret_cast<const void *>(fn), k * threads, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        const int granules = (int)(((size_t)k * lds_stride + 1279) / 1280);
+        const int by_lds = 128 / granules;
+        const int entries = (by_regs < by_lds ? by_regs : by_lds) * k;
+        if (entries > best_entries) { best_entries = entries; best = k; }
+    }
+    return best;
+}
+
 int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t stream)
 {
     if (!ctx) return fail(SAT_EINVAL, "null context");
@@ -318,7 +345,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
 #endif
 
     struct Planned {
-        kernel_fn fn; SatKernelArgs args; int count, nqc, threads, n2max, max_entries; size_t lds, slab_words;
+        kernel_fn fn; SatKernelArgs args; int count, nqc, threads, n2max, max_entries, epw; size_t lds, slab_words;
         int n1p, m2w, qlds, opt, wpl;            // the instantiation's template arguments (sat_last_launch_info)
     };
     std::vector<Planned> plan;
@@ -401,7 +428,17 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
             a.entry_list = ctx->d_lists + (one_launch ? 0 : ctx->bucket_begin[b]);
+            // entries per workgroup (see pick_epw); small launches keep one, for the most workgroups
+            const size_t lds_stride = (lds + 15) & ~(size_t)15;
+            int epw = 1;
+            if ((long long)count * nqc >= 8192) epw = pick_epw(fn, threads, lds_stride);
+            if (ctx->tune.epw >= 1 && (size_t)ctx->tune.epw * lds_stride <= kLdsLimit && ctx->tune.epw * threads <= 1024)
+                epw = ctx->tune.epw;
+            a.epw = epw;
+            a.tpe = threads;
+            a.lds_stride = (uint32_t)lds_stride;
             Planned pl;
+            pl.epw = epw;
             pl.fn = fn;
             pl.args = a;
             pl.count = count;
@@ -444,7 +481,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             pl.max_entries = (int)(fit / (size_t)qn_cap);
             if (pl.max_entries < 1) pl.max_entries = 1;
             if (pl.max_entries > pl.count) pl.max_entries = pl.count;
-            const size_t need = pl.slab_words * (size_t)pl.max_entries * (size_t)qn_cap;
+            // (the spare slots of a launch's last workgroup have slabs too)
+            const size_t need = pl.slab_words * (size_t)(pl.max_entries + pl.epw - 1) * (size_t)qn_cap;
             if (need > need_total) need_total = need;
         }
         need_total *= (size_t)nlanes;                                  // one region per lane of launches
@@ -473,7 +511,9 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                     part.bmap_slabs = ctx->d_bmap_slabs + (size_t)lane * lane_region_words;
                     part.bmap_slab_words = (uint32_t)pl.slab_words;
                 }
-                hipLaunchKernelGGL(pl.fn, dim3(en, qn), dim3(pl.threads), pl.lds, s, part);
+                part.n_list = en;
+                const size_t lds_launch = pl.epw > 1 ? (size_t)pl.epw * pl.args.lds_stride : pl.lds;
+                hipLaunchKernelGGL(pl.fn, dim3((en + pl.epw - 1) / pl.epw, qn), dim3(pl.threads * pl.epw), lds_launch, s, part);
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -488,9 +528,9 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     ctx->last_launch_info.clear();
     for (size_t i = 0; i < plan.size(); i++) {
         char buf[160];
-        snprintf(buf, sizeof buf, "%ssat_sa_kernel<%d, %d, %s, %d, %d> grid %d x %d block %d lds %zu", i ? "; " : "", plan[i].n1p,
-                 plan[i].m2w, plan[i].qlds ? "true" : "false", plan[i].opt, plan[i].wpl, plan[i].count, plan[i].nqc,
-                 plan[i].threads, plan[i].lds);
+        snprintf(buf, sizeof buf, "%ssat_sa_kernel<%d, %d, %s, %d, %d> grid %d x %d block %d x %d lds %zu", i ? "; " : "", plan[i].n1p,
+                 plan[i].m2w, plan[i].qlds ? "true" : "false", plan[i].opt, plan[i].wpl,
+                 (plan[i].count + plan[i].epw - 1) / plan[i].epw, plan[i].nqc, plan[i].epw, plan[i].threads, plan[i].lds);
         ctx->last_launch_info += buf;
     }
 #ifdef SAT_PHASE_TIMING
@@ -585,6 +625,7 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         ctx->tune.streams = env_int("SAT_EXP_STREAMS", -1);
         ctx->tune.upload_threads = env_int("SAT_EXP_UPLOAD_THREADS", 0);
         ctx->tune.upload_timing = env_int("SAT_EXP_UPLOAD_TIMING", 0);
+        ctx->tune.epw = env_int("SAT_EXP_EPW", 0);
         const int pad = env_int("SAT_EXP_LDS_PAD", 0);
         ctx->tune.lds_pad = pad > 0 ? (size_t)pad : 0;
         if (ctx->tune.streams != 0) {
@@ -933,12 +974,12 @@ unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx) { return ctx ? ctx->d2
 const char *sat_last_launch_info(const sat_ctx *ctx) { return ctx ? ctx->last_launch_info.c_str() : ""; }
 
 void sat_debug_lds_layout(int split, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
-                          uint32_t out[9])
+                          uint32_t out[11])
 {
     const satk::LdsLayout L = satk::lds_layout(split != 0, n2, satk::map_words((n1 + 3) >> 2), n1p, chains, threads,
                                                q_in_lds != 0, compact != 0);
-    const uint32_t v[9] = { L.code, L.qdist, L.qcode, L.smap, L.tmask, L.qtypes, L.red, L.items, L.total };
-    for (int i = 0; i < 9; i++) out[i] = v[i];
+    const uint32_t v[11] = { L.code, L.qdist, L.qcode, L.smap, L.tmask, L.qtypes, L.leader, L.red, L.red_stride, L.items, L.total };
+    for (int i = 0; i < 11; i++) out[i] = v[i];
 }
 
 int sat_sync(sat_ctx *ctx)

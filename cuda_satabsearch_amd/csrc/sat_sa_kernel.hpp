@@ -113,7 +113,13 @@ struct SatKernelArgs {
     const uint8_t  *tab_tri;      // packed lower triangles, code bytes
     const float    *dist_tri;     // packed lower triangles, distances
     const uint32_t *ordinal;      // [N] db file-order ordinal (stream key)
-    const int32_t  *entry_list;   // entries handled by this launch (one per workgroup)
+    const int32_t  *entry_list;   // entries handled by this launch
+    int32_t         n_list;       // how many
+    // A workgroup holds `epw` entries side by side: entry slot s = threads [s * tpe, (s + 1) * tpe) with its
+    // own LDS carve at s * lds_stride.  The slots share nothing but the three workgroup barriers; the
+    // host picks epw so that the CU's 128 LDS granules of 1280 bytes hold the most entries.
+    int32_t         epw, tpe;
+    uint32_t        lds_stride;   // bytes, a multiple of 16
     // queries of this launch's size class
     const SatQuery *queries;
     // options
@@ -373,7 +379,9 @@ struct LdsLayout {
     uint32_t smap;        // chain maps, word-interleaved [word][chain], row stride chains + 1
     uint32_t tmask;       // [4 types][4 words] db SSEs of a type
     uint32_t qtypes;      // query SSE types
-    uint32_t red;         // 16 reduction keys + the LSOLN leader key (64-bit)
+    uint32_t leader;      // the LSOLN leader key (64-bit)
+    uint32_t red;         // the waves' arg-max keys (64-bit), red_stride bytes apart
+    uint32_t red_stride;
     uint32_t items;       // per-wave item tables of the work compaction
     uint32_t total;
 };
@@ -381,7 +389,9 @@ __host__ __device__ inline LdsLayout lds_layout(bool split, int n2, int words, i
                                                  bool q_in_lds, bool compact)
 {
     LdsLayout L;
-    uint32_t dcells = (uint32_t)(n2 + 1) * (uint32_t)(n2 + 1);
+    // rows 0 .. n2-1 of the cell matrix, columns 0 .. n2: the null SSE (index n2) has a column - map bytes
+    // of unmatched query SSEs point at it - but no row: a null image scores 0 and its row is never summed
+    uint32_t dcells = (uint32_t)n2 * (uint32_t)(n2 + 1);
     uint32_t off;
     if (split) {                                              // 4-byte distances + 1-byte codes (see DbRow)
         dcells = (dcells + 3u) & ~3u;
@@ -400,12 +410,17 @@ __host__ __device__ inline LdsLayout lds_layout(bool split, int n2, int words, i
     // an even word count keeps what follows 8-byte aligned
     off += (((uint32_t)words * (uint32_t)(chains + 1) + 1u) & ~1u) * 4u;
     L.tmask = off;
-    off += 16u * 4u;
+    off += (split ? 16u : 4u) * 4u;                           // one word per type up to 32 db SSEs, else four
     L.qtypes = off;
     off += ((uint32_t)n1p + 15u) & ~15u;
     off = (off + 7u) & ~7u;
+    L.leader = off;
+    off += 8u;
+    // the arg-max key of wave w: with item tables, the first 8 bytes of the wave's own table (it is done
+    // with the table by then, and no other wave touches it); without, an array of 16 keys
     L.red = off;
-    off += 17u * 8u;
+    L.red_stride = compact ? 256u : 8u;
+    if (!compact) off += 16u * 8u;
     L.items = off;
     if (compact) off += (uint32_t)((threads + 63) / 64) * 64u * 4u;      // compaction handles <= 64 rows per wave
     L.total = off;
@@ -481,8 +496,15 @@ sat_sa_kernel(const SatKernelArgs a)
     constexpr int M1W = (N1P + 31) / 32;
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
-    const int lane_id = threadIdx.x;
-    const int nthreads = blockDim.x;
+    // entry slot of this wave (wave-uniform: tpe is a multiple of 64) and the lane inside it
+    const int nthreads = a.tpe;
+    const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slot = a.epw > 1 ? wave_wg / (nthreads >> 6) : 0;
+    const int wlane = (int)(threadIdx.x & 63u);
+    const int lane_id = ((wave_wg - slot * (nthreads >> 6)) << 6) | wlane;
+    __builtin_assume(lane_id >= 0 && lane_id < 1024);
+    const uint32_t lds_base = (uint32_t)slot * a.lds_stride;
+    unsigned char *const lds_slot = lds_raw + lds_base;
     // chain = restart slot of this lane; `part` of `lpc` adjacent lanes share one chain
     constexpr bool FAST = OPT >= 0;
     const int lpc_shift = FAST ? (OPT >> 2) : a.lpc_shift;      // OPT bits 2-3: log2(lanes per chain), 0..2
@@ -492,7 +514,9 @@ sat_sa_kernel(const SatKernelArgs a)
     const int tid = lane_id >> lpc_shift;         // chain index inside the workgroup
     const int part = lane_id & (lpc - 1);
     const int T = nthreads >> lpc_shift;          // chains per workgroup
-    const int e = a.entry_list[blockIdx.x];
+    // the last workgroup's spare slots repeat the last entry (same result, written twice)
+    const int list_pos = (int)blockIdx.x * a.epw + slot;
+    const int e = a.entry_list[min(list_pos, a.n_list - 1)];
     const SatQuery Q = a.queries[blockIdx.y];
     const int n1 = Q.n1;
     const int n2 = a.orders[e];
@@ -513,38 +537,40 @@ sat_sa_kernel(const SatKernelArgs a)
     // goes by the launch's size class, not by this entry's order (n2max > 32 <=> M2W > 1).
     constexpr bool SPLIT = M2W > 1;
     const LdsLayout lay = lds_layout(SPLIT, n2, cmp_words, N1P, T, nthreads, QLDS, opt_compact);
-    uint2 *Dc = reinterpret_cast<uint2 *>(lds_raw);                          // !SPLIT: 8-byte cells
-    float *distL = reinterpret_cast<float *>(lds_raw);                       // SPLIT: distances ...
-    uint8_t *codeL = lds_raw + lay.code;                                     // ... and code bytes
+    uint2 *Dc = reinterpret_cast<uint2 *>(lds_slot);                          // !SPLIT: 8-byte cells
+    float *distL = reinterpret_cast<float *>(lds_slot);                       // SPLIT: distances ...
+    uint8_t *codeL = lds_slot + lay.code;                                     // ... and code bytes
     auto db_row = [&](int j) -> DbRow<SPLIT> {
         if constexpr (SPLIT) return DbRow<true>{ distL + __mul24(j, n2p), codeL + __mul24(j, n2p) };
         else return DbRow<false>{ Dc + __mul24(j, n2p) };
     };
     // query groups in LDS cover the padding words too (sentinel cells, like every group past n1w)
-    float4 *qdistL = reinterpret_cast<float4 *>(lds_raw + lay.qdist);
-    uint32_t *qcodeL = reinterpret_cast<uint32_t *>(lds_raw + lay.qcode);
-    uint32_t *smap = reinterpret_cast<uint32_t *>(lds_raw + lay.smap);
+    float4 *qdistL = reinterpret_cast<float4 *>(lds_slot + lay.qdist);
+    uint32_t *qcodeL = reinterpret_cast<uint32_t *>(lds_slot + lay.qcode);
+    uint32_t *smap = reinterpret_cast<uint32_t *>(lds_slot + lay.smap);
     // map word w of chain c lives at w*TP + c with TP = T + 1: the odd stride puts the words of
     // one chain in different banks (the compacted loop reads them from several lanes at once) and
     // keeps word w of all chains contiguous for the static loops
     const int TP = T + 1;
-    uint32_t *tmask = reinterpret_cast<uint32_t *>(lds_raw + lay.tmask);
+    uint32_t *tmask = reinterpret_cast<uint32_t *>(lds_slot + lay.tmask);
     // best maps: word w of chain c at w*T + c of this workgroup's slab (global memory)
-    uint32_t *bmap = lsoln ? a.bmap_slabs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.bmap_slab_words : nullptr;
-    uint8_t *qtypes = lds_raw + lay.qtypes;
-    unsigned long long *red = reinterpret_cast<unsigned long long *>(lds_raw + lay.red);
+    uint32_t *bmap = lsoln ? a.bmap_slabs + ((size_t)blockIdx.y * gridDim.x * a.epw + list_pos) * a.bmap_slab_words : nullptr;
+    uint8_t *qtypes = lds_slot + lay.qtypes;
+    unsigned char *red_b = lds_slot + lay.red;
+    auto red_key = [&](int w) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(red_b + (uint32_t)w * lay.red_stride); };
+    constexpr int TMS = M2W == 1 ? 1 : 4;                     // words per type of the type masks
     // explicit LDS address space: these two are written by some lanes and read by others of the
     // same wave between wavefront-scope fences, and must stay ds_* instructions
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     typedef __attribute__((address_space(3))) int32_t lds_i32_t;
-    const uint32_t items_off = lay.items;
+    const uint32_t items_off = lds_base + lay.items;
     // LSOLN: key (score, restart) of the best proposal any chain of the workgroup has recorded so
     // far, same form as the final arg-max key.  A chain copies its map out only when its new best
     // beats this leader: the map that is finally output belongs to the chain with the largest key,
     // and that chain's last own-best proposal always beats every key recorded before it (a stale,
     // lower leader only causes a spare copy).  ~1150 copies per workgroup become ~20.
     typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
-    lds_u64_t *leader = (lds_u64_t *)(uintptr_t)(lay.red + 16u * 8u);
+    lds_u64_t *leader = (lds_u64_t *)(uintptr_t)(lds_base + lay.leader);
     auto beats_leader = [&](int sc, int restart_) -> bool {
         const unsigned long long key = (((unsigned long long)(uint32_t)(sc + 0x40000000)) << 32) | (0xFFFFFFFFu - (uint32_t)restart_);
         if (key <= *leader) return false;
@@ -599,12 +625,12 @@ sat_sa_kernel(const SatKernelArgs a)
     {
         const uint8_t *tt = a.tab_tri + a.cell_off[e];
         const float *dd = a.dist_tri + a.cell_off[e];
-        const int total = n2p * n2p;
+        const int total = n2 * n2p;
         for (int c = lane_id; c < total; c += nthreads) {
             int j = c / n2p;
             int l = c - j * n2p;
             uint2 cell;
-            if (j < n2 && l < n2) {
+            if (l < n2) {
                 int hi = j > l ? j : l, lo = j > l ? l : j;
                 int t = hi * (hi + 1) / 2 + lo;
                 const float v = dd[t];
@@ -622,8 +648,8 @@ sat_sa_kernel(const SatKernelArgs a)
                 Dc[c] = cell;
             }
         }
-        if (lane_id < 16) tmask[lane_id] = 0u;
-        if (lane_id == 0) red[16] = 0ull;                     // LSOLN leader key
+        if (lane_id < 4 * TMS) tmask[lane_id] = 0u;
+        if (lane_id == 0) *reinterpret_cast<unsigned long long *>(lds_slot + lay.leader) = 0ull;   // LSOLN leader key
         for (int i = lane_id; i < N1P; i += nthreads) qtypes[i] = Q.qtypes[i];
         if (QLDS) {
             const int groups = cmp_words * N1P;
@@ -636,7 +662,7 @@ sat_sa_kernel(const SatKernelArgs a)
     __syncthreads();
     for (int j = lane_id; j < n2; j += nthreads) {
         int t = a.tab_tri[a.cell_off[e] + (int64_t)j * (j + 1) / 2 + j] & 3;   // diagonal = SSE type
-        atomicOr(&tmask[t * 4 + (j >> 5)], 1u << (j & 31));
+        atomicOr(&tmask[t * TMS + (j >> 5)], 1u << (j & 31));
     }
     __syncthreads();
 
@@ -658,7 +684,7 @@ sat_sa_kernel(const SatKernelArgs a)
     // 16-bit reciprocal (exact for lane <= 64); lane -> (item of the round, first map word).
     const int cmp_recip = (65536 + cmp_lpi - 1) / cmp_lpi;
     const int per_round = (64 * cmp_recip) >> 16;
-    const int sub = __mul24(lane_id & 63, cmp_recip) >> 16, kw = (lane_id & 63) - __mul24(sub, cmp_lpi);
+    const int sub = __mul24(wlane, cmp_recip) >> 16, kw = wlane - __mul24(sub, cmp_lpi);
     const bool lane_ok = sub < per_round;
     // tail shapes: one word per lane (n1w lanes per row) and two words per lane, used for the last
     // rows of a step when they fit one round of that shape; the two-word shape only if its padded
@@ -697,7 +723,7 @@ sat_sa_kernel(const SatKernelArgs a)
                             const int t = qtypes[i];
                             Bits<M2W> cand, below = bits_below<M2W>(j);
 #pragma unroll
-                            for (int w = 0; w < M2W; w++) cand.w[w] = tmask[t * 4 + w] & ~below.w[w];
+                            for (int w = 0; w < M2W; w++) cand.w[w] = tmask[t * TMS + w] & ~below.w[w];
                             int jj = bits_lowest<M2W>(cand);
                             if (jj < 0) {
                                 stopped = true;              // K.cu:633-638: give up, no more draws used
@@ -716,14 +742,17 @@ sat_sa_kernel(const SatKernelArgs a)
         // ---- full score of the initial map (tmscord, K.cu:396-440): pairs i < k
         int score = 0;
         for (int i = 0; i < n1 - 1; i++) {
+            // an unmatched SSE has no row in LDS: its lane walks row 0 and drops the sum
             const int j = smap_b[map_byte_addr(i)];
-            const DbRow<SPLIT> drow = db_row(j);
+            const bool jreal = j != NULLJ;
+            const DbRow<SPLIT> drow = db_row(jreal ? j : 0);
+            int rowsum = 0;
             auto row_group = [&](int kw) {
                 // pairs with k <= i inside the first word are switched off (mask from i and kw)
                 const int below = i + 1 - 4 * kw;
                 const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
                 const uint32_t qi = (uint32_t)(kw * N1P + i);
-                score = quad_terms(load_qdist(qi), load_qcode(qi), drow, smap[kw * TP + tid], force, score);
+                rowsum = quad_terms(load_qdist(qi), load_qcode(qi), drow, smap[kw * TP + tid], force, rowsum);
             };
             // one lane per chain: the group index stays in scalar registers, and so do the query cells
             if (lpc == 1) {
@@ -731,11 +760,12 @@ sat_sa_kernel(const SatKernelArgs a)
                     const int below = i + 1 - 4 * kw;
                     const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
                     const uint32_t qi = (uint32_t)(kw * N1P + i);
-                    score = quad_terms(load_qdist_uniform(qi), load_qcode_uniform(qi), drow, smap[kw * TP + tid], force, score);
+                    rowsum = quad_terms(load_qdist_uniform(qi), load_qcode_uniform(qi), drow, smap[kw * TP + tid], force, rowsum);
                 }
             } else {
                 for (int kw = ((i + 1) >> 2) + part; kw < n1w; kw += lpc) row_group(kw);
             }
+            score += jreal ? rowsum : 0;
         }
         if (lpc >= 2) score += __shfl_xor(score, 1, 64);
         if (lpc == 4) score += __shfl_xor(score, 2, 64);
@@ -808,7 +838,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 // no mapped SSE at or below ssei: startj = n2, empty (K.cu:1060-1063); no mapped
                 // successor: endj = -1, empty, unless ssei is the last query SSE (K.cu:1064-1077)
                 const bool empty = none || (y == 0u && ssei != n1 - 1);
-                cand.w[0] = empty ? 0u : (tmask[qtypes[ssei] * 4] & gap);
+                cand.w[0] = empty ? 0u : (tmask[qtypes[ssei]] & gap);
             } else {
                 oldj = smap_b[map_byte_addr(ssei)];
                 int startj = 0, endj = n2;
@@ -830,7 +860,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 Bits<M2W> lo = bits_below<M2W>(startj), hi = bits_below<M2W>(endj);
 #pragma unroll
                 for (int w = 0; w < M2W; w++)
-                    cand.w[w] = tmask[t * 4 + w] & ~occ.w[w] & hi.w[w] & ~lo.w[w];
+                    cand.w[w] = tmask[t * TMS + w] & ~occ.w[w] & hi.w[w] & ~lo.w[w];
             }
             // no candidate: the SSE becomes unmatched; one: it is taken without a draw
             // (K.cu:701-702); several: the draw picks the (u - EPS) * cnt -th (K.cu:705-711).
@@ -950,12 +980,12 @@ sat_sa_kernel(const SatKernelArgs a)
                         if (cmp_wpl > 1 && rest <= tail1_rows) {
                             // (lane -> (row, word) of a tail shape is worked out here every time: hoisted out
                             // of the step loop these values would sit in registers the main shape needs)
-                            int l = lane_id & 63;
+                            int l = wlane;
                             asm volatile("" : "+v"(l));
                             const int rsub = __mul24(l, tail1_recip) >> 16;
                             one_round(std::integral_constant<int, 1>{}, first, n1w, rsub, l - __mul24(rsub, n1w), rsub < tail1_rows);
                         } else if (cmp_wpl > 2 && rest <= tail2_rows) {
-                            int l = lane_id & 63;
+                            int l = wlane;
                             asm volatile("" : "+v"(l));
                             const int rsub = __mul24(l, tail2_recip) >> 16;
                             one_round(std::integral_constant<int, 2>{}, first, tail2_lpi, rsub, l - __mul24(rsub, tail2_lpi), rsub < tail2_rows);
@@ -971,10 +1001,11 @@ sat_sa_kernel(const SatKernelArgs a)
                     if (nitems >= 1) delta = (int)(items[pre] - item1);
                     if (nitems == 2) delta += (int)(items[pre + 1] - item2);
                     // with several lanes per chain only part 0 listed rows: hand its sum to the others
-                    if (lpc > 1) delta = __shfl(delta, (lane_id & 63) & ~(lpc - 1), 64);
+                    if (lpc > 1) delta = __shfl(delta, wlane & ~(lpc - 1), 64);
                 } else {
                     // dense regime: every lane scores its own two rows
-                    const DbRow<SPLIT> orow = db_row(oldj), nrow = db_row(newj);
+                    // (a null image has no row: row 0 stands in and the sum is dropped)
+                    const DbRow<SPLIT> orow = db_row(oreal ? oldj : 0), nrow = db_row(nreal ? newj : 0);
                     int sum_new = 0, sum_old = 0;
                     auto move_group = [&](int kw) {
                         const uint32_t word = smap[kw * TP + tid];
@@ -986,7 +1017,7 @@ sat_sa_kernel(const SatKernelArgs a)
                     };
                     if (lpc == 1) for (int kw = 0; kw < n1w; kw++) move_group(kw);
                     else for (int kw = part; kw < n1w; kw += lpc) move_group(kw);
-                    delta = sum_new - sum_old;
+                    delta = (nreal ? sum_new : 0) - (oreal ? sum_old : 0);
                     if (lpc >= 2) delta += __shfl_xor(delta, 1, 64);
                     if (lpc == 4) delta += __shfl_xor(delta, 2, 64);
                 }
@@ -1064,10 +1095,10 @@ sat_sa_kernel(const SatKernelArgs a)
         key = other > key ? other : key;
     }
     const int wave = lane_id >> 6, nwaves = (nthreads + 63) >> 6;
-    if ((lane_id & 63) == 0) red[wave] = key;
+    if (wlane == 0) *red_key(wave) = key;
     __syncthreads();
-    unsigned long long win = red[0];
-    for (int w = 1; w < nwaves; w++) win = red[w] > win ? red[w] : win;
+    unsigned long long win = *red_key(0);
+    for (int w = 1; w < nwaves; w++) win = *red_key(w) > win ? *red_key(w) : win;
 
     const uint32_t win_restart = 0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu);
     if (lane_id == 0) Q.scores[e] = (int)(uint32_t)(win >> 32) - 0x40000000;

@@ -229,13 +229,14 @@ unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx);
 const char *sat_last_launch_info(const sat_ctx *ctx);
 
 /*
- * Diagnostics: the LDS carve of one workgroup of the SA kernel (csrc/sat_sa_kernel.hpp, lds_layout -
- * the one function both the kernel and the launch sizing use), byte offsets out[0..8] = code bytes,
- * query distances, query codes, chain maps, type masks, query types, reduction keys, item tables,
- * total.  Lets tests assert alignment and monotonicity without a GPU.
+ * Diagnostics: the LDS carve of one entry slot of the SA kernel (csrc/sat_sa_kernel.hpp, lds_layout -
+ * the one function both the kernel and the launch sizing use), byte offsets out[0..10] = code bytes,
+ * query distances, query codes, chain maps, type masks, query types, LSOLN leader key, the waves'
+ * arg-max keys, the byte stride between those keys (256: inside the item tables), item tables, total.
+ * Lets tests assert alignment and monotonicity without a GPU.
  */
 void sat_debug_lds_layout(int split, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
-                          uint32_t out[9]);
+                          uint32_t out[11]);
 
 /*
  * ---- one search over several GPUs of a node, driven from one host thread -------------------------
