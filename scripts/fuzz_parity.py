@@ -30,7 +30,8 @@ if True:
         lorder, lsoln = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         r = int(rng.choice([1, 7, 64, 65, 128, 200, 300]))
         qord = int(rng.integers(0, 5))
-        for k, v in (("SAT_EXP_LPC", rng.choice(["", "0", "1", "2"])), ("SAT_EXP_COMPACT", rng.choice(["", "0", "1"]))):
+        for k, v in (("SAT_EXP_LPC", rng.choice(["", "0", "1", "2"])), ("SAT_EXP_COMPACT", rng.choice(["", "0", "1"])),
+                     ("SAT_EXP_EPW", rng.choice(["", "", "2", "3", "4"]))):
             if v: os.environ[k] = str(v)
             else: os.environ.pop(k, None)
         # the launch-heuristic overrides are read when a context is created: one context per case
@@ -50,7 +51,7 @@ if True:
         cases += 1
         if not ok:
             print("MISMATCH", dict(n=n, lo=lo, hi=hi, src=src, keep=keep, lorder=lorder, lsoln=lsoln, r=r, qord=qord,
-                                   env={k: os.environ.get(k) for k in ("SAT_EXP_LPC", "SAT_EXP_COMPACT")}))
+                                   env={k: os.environ.get(k) for k in ("SAT_EXP_LPC", "SAT_EXP_COMPACT", "SAT_EXP_EPW")}))
             print(np.nonzero(sc != osc)[0][:10], sc[sc != osc][:10], osc[sc != osc][:10])
             sys.exit(1)
 print(f"fuzz ok: {cases} random cases in {time.time()-t0:.0f}s")

@@ -135,6 +135,34 @@ def test_forced_execution_modes(monkeypatch, env):
             check(forced, db, q, False, True, 100)
 
 
+@pytest.mark.parametrize("epw", [2, 3, 4])
+def test_several_entries_per_workgroup(monkeypatch, epw):
+    """Big launches put 2+ entries into one workgroup (entry slots with their own LDS carve; the host picks
+    the count from the CU's LDS granules).  Forced here on small databases whose entry counts leave spare
+    slots in the last workgroup: scores and solution maps must be the oracle's for every slot count, for a
+    query batch (slabs of best maps per slot and query), and for large entries with several lanes per chain."""
+    monkeypatch.setenv("SAT_EXP_EPW", str(epw))
+    db = sat.synth.make_db(151, 6, 40, seed=33)
+    big = sat.synth.make_db(23, 70, 111, sort=True, seed=34)
+    with sat.Searcher(0) as s:
+        s.upload(db)
+        q = sat.synth.planted_query(db, 120, keep=0.9)
+        check(s, db, q, True, True, 128)
+        check(s, db, q, False, True, 70)
+        check(s, db, q, True, False, 128)
+        assert f"block {epw} x " in s.last_launch_info()
+        queries = [sat.synth.planted_query(db, src, keep=0.8, seed=src) for src in (3, 77, 150)]
+        s.set_queries(queries, 2)
+        scores, maps, _ = s.search(True, True, 128)
+        for qi, (qt, qd, qty) in enumerate(queries):
+            osc, omp, _ = oracle_lib.search(db, qt, qd, qty, True, True, 128, query_ordinal=2 + qi)
+            assert np.array_equal(scores[qi], osc), f"query {qi}"
+            assert np.array_equal(maps[qi], omp), f"maps of query {qi}"
+        s.upload(big)
+        qb = sat.synth.planted_query(big, 20, keep=0.6)
+        check(s, big, qb, True, True, 128)
+
+
 @pytest.mark.parametrize("general", [False, True], ids=["specialised", "general"])
 def test_round_shapes_of_every_query_order_class(wide_db, monkeypatch, general):
     """The compacted rounds serve a listed row with ceil(n1w/4) lanes x up to 4 map words, pad the
