@@ -1,9 +1,13 @@
 """Condense a scripts/profile_bench.sh output directory into profiles/<name>.* files:
 the rocprofv3 --kernel-trace --stats CSV as it is and a text table of the PMC counters
-(mean per dispatch of the SA kernel) with the derived per-launch figures."""
+(mean per dispatch of the SA kernel) with the derived per-launch figures.
+python scripts/summarize_prof.py gpurun_out/prof_TAG NAME [entries per launch]"""
 import collections, csv, glob, os, shutil, sys
 
 src, name = sys.argv[1], sys.argv[2]
+# db entries per launch: a workgroup may hold several entries (sat_last_launch_info), so the dispatch's
+# grid alone does not say; default = the bench shard
+entries_per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 125000
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -53,7 +57,7 @@ if "FETCH_SIZE" in vals:
     lines.append(f"derived: HBM traffic per launch = {fetch/1e6:.1f} MB read (FETCH_SIZE x 1024 x 2) + {wr/1e6:.2f} MB written")
 if "FETCH_SIZE" in vals:
     import json
-    json.dump({"source": name + "_summary.txt", "entries_per_launch": int(vals["meta"]["Grid_Size"]) // int(vals["meta"]["Workgroup_Size"]) if "meta" in vals else None,
+    json.dump({"source": name + "_summary.txt", "entries_per_launch": entries_per_launch,
                "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals.get("WRITE_SIZE", 0.0),
                "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals.get("WRITE_SIZE", 0.0) * 1024,
                "valu_wave_instr_per_launch": vals.get("SQ_INSTS_VALU"), "lds_wave_instr_per_launch": vals.get("SQ_INSTS_LDS"),
