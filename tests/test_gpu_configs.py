@@ -142,6 +142,44 @@ def test_config4_large_query_lsoln_100k(golden_dir):
     print(f"\nconfigs[4] 101-SSE query x {n} entries (8..111 SSEs), LSOLN=T, r=128: {ms:.1f} ms -> {n / ms * 1e3:,.0f} scorings/s")
 
 
+def test_motif_workflow_without_order_constraint_r4096(c2_db, golden_dir):
+    """the substructure-motif workflow (scripts/qptabmatchstructs.sh:135-137, 156 runs
+    `T F T` with -r4096): the reference's 9-SSE sheet motif and an 8-SSE non-sequential motif cut out of a
+    database member, LORDER = F, LSOLN = T, r = 4096, against 100 000 entries - the [0, n2) candidate window
+    (K.cu:1079-1083) and solution maps at scale.  Sampled entries equal the oracle bit for bit, maps are
+    injective and inside the entry but need not be ordered, and the member the motif was cut from is on top."""
+    n = len(c2_db)
+    name, t, d, ty = workloads.load_queries("1qlp_sheetbc.input", golden_dir)[0]
+    src = 91_234
+    st, sd = c2_db.dense(src)
+    pick = np.random.default_rng(9).permutation(int(c2_db.orders[src]))[:8]      # not in sequence order
+    cut = (st[np.ix_(pick, pick)].copy(), sd[np.ix_(pick, pick)].copy(), np.diagonal(st)[pick].copy())
+    sample = workloads.sample_entries(n, 16, seed=6)
+    with sat.Searcher(0) as s:
+        s.upload(c2_db)
+        s.set_queries([(t, d, ty), cut], 0)
+        a, amaps, ms = s.search(False, True, 4096)
+        b, bmaps, _ = s.search(False, True, 4096)
+    assert np.array_equal(a, b) and np.array_equal(amaps, bmaps)
+    unordered = 0
+    for qi, q in enumerate([(t, d, ty), cut]):
+        n1 = len(q[2])
+        osc, omaps, _ = oracle_lib.search(c2_db, *q, False, True, 4096, entries=sample, query_ordinal=qi)
+        assert np.array_equal(a[qi][sample], osc), f"query {qi}"
+        assert np.array_equal(amaps[qi][sample], omaps), f"maps of query {qi}"
+        assert np.abs(a[qi]).max() <= score_bound(n1)
+        for e in sample:
+            img = amaps[qi][e][:n1]
+            img = img[img >= 0]
+            assert len(set(img.tolist())) == len(img) and (img < c2_db.orders[e]).all()
+            unordered += int((np.diff(img) < 0).any())
+        assert (amaps[qi][:, n1:] == -1).all()
+    assert unordered > 0                                   # the order constraint really is off
+    assert a[1][src] == a[1].max() == score_bound(8)       # the cut motif matches its source exactly
+    assert np.array_equal(np.sort(amaps[1][src][:8]), np.sort(pick))
+    print(f"\nmotif workflow: 2 motifs (9, 8 SSEs) x {n} entries, T F T, r=4096: {ms:.1f} ms -> {2 * n / ms * 1e3:,.0f} scorings/s")
+
+
 def test_mixed_size_database_throughput_and_stream_overlap(monkeypatch):
     """A size-sorted database with orders uniform on [8, 32] (C3): the order buckets of a search
     run concurrently on side streams; queueing them one after the other instead must give the same
