@@ -431,7 +431,12 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             // entries per workgroup (see pick_epw); small launches keep one, for the most workgroups
             const size_t lds_stride = (lds + 15) & ~(size_t)15;
             int epw = 1;
-            if ((long long)count * nqc >= 8192) epw = pick_epw(fn, threads, lds_stride);
+            if ((long long)count * nqc >= 8192) {
+                const auto key = std::make_tuple(reinterpret_cast<const void *>(fn), threads, lds_stride);
+                auto it = ctx->epw_choice.find(key);
+                if (it == ctx->epw_choice.end()) it = ctx->epw_choice.emplace(key, pick_epw(fn, threads, lds_stride)).first;
+                epw = it->second;
+            }
             if (ctx->tune.epw >= 1 && (size_t)ctx->tune.epw * lds_stride <= kLdsLimit && ctx->tune.epw * threads <= 1024)
                 epw = ctx->tune.epw;
             a.epw = epw;

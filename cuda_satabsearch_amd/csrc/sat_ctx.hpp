@@ -4,7 +4,9 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
+#include <tuple>
 #include <unordered_set>
 #include <vector>
 
@@ -51,6 +53,8 @@ struct sat_ctx {
     struct Tuning { int compact = -1, qlds = -1, lpc = -1, general = 0, streams = -1, upload_threads = 0, upload_timing = 0, epw = 0; size_t lds_pad = 0; } tune;
     // kernel instantiations whose dynamic-LDS limit has been raised on this device
     std::unordered_set<const void *> lds_attr_done;
+    // entries per workgroup chosen for (instantiation, threads per entry, LDS bytes per entry): asked once
+    std::map<std::tuple<const void *, int, size_t>, int> epw_choice;
     // side streams: the order buckets of one search run concurrently (each launch has a tail of
     // half-empty CUs; the next bucket's workgroups fill it), forked from / joined to `stream`
     hipStream_t side_stream[kNumBuckets] = { nullptr };
