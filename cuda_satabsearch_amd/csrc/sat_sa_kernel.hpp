@@ -1,18 +1,22 @@
 // sat_sa_kernel.hpp - the simulated-annealing tableau search kernel for gfx950 (CDNA4).
 //
-// One workgroup scores ONE database structure against the query; every lane runs an
-// independent restart chain (lane = restart, as the reference maps threadIdx to
-// restarts, K.cu:1012-1015), 100 Metropolis steps each.  Written from scratch for
+// One ENTRY SLOT of a workgroup scores ONE database structure against the query; every lane runs
+// an independent restart chain (lane = restart, as the reference maps threadIdx to restarts,
+// K.cu:1012-1015), 100 Metropolis steps each.  A workgroup is one slot, or several side by side
+// (own threads, own LDS carve, shared barriers only) where that packs more entries into the CU's
+// 128 LDS granules of 1280 bytes - the host decides per launch (sat_capi.hip pick_epw).  Written from scratch for
 // 64-wide wavefronts and the 160 KB LDS; what it computes follows the reference
 // kernel body K.cu:924-1233 (K.cu = nvcc_src_current/cudaSaTabsearch_kernel.cu).
 //
 // Data layout
-//   Dc   (LDS) (n2+1) x (n2+1) 8-byte cells {f32 distance, u32 code byte} of the db
-//        entry, expanded from the packed lower triangle in HBM.  Row n2 and column n2
-//        are a "null" SSE whose distance is the sentinel -1e30: an unmatched query SSE
+//   Dc   (LDS) n2 x (n2+1) 8-byte cells {f32 distance, u32 code byte} of the db
+//        entry, expanded from the packed lower triangle in HBM.  Column n2 is a "null"
+//        SSE whose distance is the sentinel -1e30: an unmatched query SSE
 //        is represented as matched to the null SSE, so |d1 - d2| <= 4 is false and the
 //        pair scores 0 without any branch or predicate in the hot loop (the reference
-//        tests l >= 0, old_j >= 0, k != sse_i per pair, K.cu:521-531).
+//        tests l >= 0, old_j >= 0, k != sse_i per pair, K.cu:521-531).  The null SSE has no
+//        ROW: a null image contributes 0, the compacted rounds never list it, and the two
+//        loops that may meet one (full score, static loops) walk row 0 and drop the sum.
 //   Q    query, grouped by 4 consecutive query SSEs k (one "word" of the map) and
 //        TRANSPOSED: qdist[kw*N1P + i] = float4 of dmat1[i][4kw..4kw+3],
 //        qcode[kw*N1P + i] = the four code bytes tab1[i][4kw..4kw+3] packed in a dword.
@@ -26,9 +30,9 @@
 //        ONE chain over different banks for the compacted loop, where the lanes serving
 //        a row read that chain's words in the same instruction.
 //   bmap (LSOLN only) best map so far of every chain, same word-interleaved layout but in
-//        GLOBAL memory (one slab per workgroup of the launch): it is written on improvements
+//        GLOBAL memory (one slab per entry slot of the launch): it is written on improvements
 //        only and read once by the winner, the resident slabs (~4 KB x a few thousand
-//        workgroups) live in L2, and keeping it out of LDS keeps 12 workgroups per CU.
+//        slots) live in L2, and keeping it out of LDS keeps 12 entries per CU.
 //
 // Work compaction in the SA step (the db-scan regime is sparse: on random pairs ~25 % of
 // the query SSEs are matched, the moved SSE has a real old image in 25 % and a real new

@@ -16,7 +16,8 @@
  * not depend on them; read ONCE by sat_ctx_create, never on the search path):
  * SAT_EXP_LPC = 0|1|2 (log2 lanes per chain), SAT_EXP_COMPACT = 0|1
  * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS),
- * SAT_EXP_LDS_PAD = bytes (unused LDS added per workgroup: occupancy experiments),
+ * SAT_EXP_LDS_PAD = bytes (unused LDS added per db entry: occupancy experiments),
+ * SAT_EXP_EPW = 1..8 (db entries per workgroup; default: chosen per launch from the CU's LDS granules),
  * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones),
  * SAT_EXP_STREAMS = 0 (queue the order buckets of a search one after the other instead of
  * concurrently on side streams), SAT_EXP_UPLOAD_THREADS = n (host threads slicing the database
