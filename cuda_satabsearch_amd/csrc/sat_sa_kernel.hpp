@@ -596,16 +596,18 @@ sat_sa_kernel(const SatKernelArgs a)
     typedef const __attribute__((address_space(1))) float *gptr_f32;
     const gptr_f32 ptabG = (gptr_f32)(uintptr_t)a.ptab;
     // uniform 64-bit base + 32-bit byte offset: the saddr form of global_load, no 64-bit VALU math
-    auto load_qdist = [&](uint32_t idx) -> float4 {
-        if constexpr (QLDS) return qdistL[idx];
+    // (byte offsets: off16 = 16 * group index, off4 = 4 * group index.  The callers build them from a
+    // per-lane base plus constants, so that the words of a round differ by instruction offsets only.)
+    auto load_qdist = [&](uint32_t off16) -> float4 {
+        if constexpr (QLDS) return *reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(qdistL) + off16);
         else {
-            const f32x4_t v = *(gptr_f4)((gptr_c)qdistG + (idx << 4));
+            const f32x4_t v = *(gptr_f4)((gptr_c)qdistG + off16);
             return float4{ v.x, v.y, v.z, v.w };
         }
     };
-    auto load_qcode = [&](uint32_t idx) -> uint32_t {
-        if constexpr (QLDS) return qcodeL[idx];
-        else return *(gptr_u32)((gptr_c)qcodeG + (idx << 2));
+    auto load_qcode = [&](uint32_t off4) -> uint32_t {
+        if constexpr (QLDS) return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(qcodeL) + off4);
+        else return *(gptr_u32)((gptr_c)qcodeG + off4);
     };
     // the same cells for a wave-uniform index (the full score walks the query in step for all
     // chains): through the constant address space these are scalar loads into scalar registers
@@ -756,7 +758,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 const int below = i + 1 - 4 * kw;
                 const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
                 const uint32_t qi = (uint32_t)(kw * N1P + i);
-                rowsum = quad_terms(load_qdist(qi), load_qcode(qi), drow, smap[kw * TP + tid], force, rowsum);
+                rowsum = quad_terms(load_qdist(qi << 4), load_qcode(qi << 2), drow, smap[kw * TP + tid], force, rowsum);
             };
             // one lane per chain: the group index stays in scalar registers, and so do the query cells
             if (lpc == 1) {
@@ -933,6 +935,9 @@ sat_sa_kernel(const SatKernelArgs a)
                             const DbRow<SPLIT> drow = db_row(row);
                             float4 qd[W];
                             uint32_t qc[W], wd[W];
+                            // byte offsets of (word rkw, column si) in the two query arrays; word rkw + u * lpi is
+                            // u * lpi * N1P groups further on (an instruction offset where lpi is a constant)
+                            const uint32_t qoff4 = (uint32_t)(rkw * N1P + si) << 2, qoff16 = qoff4 << 2;
 #pragma unroll
                             for (int u = 0; u < W; u++) {
                                 // words past the map (a lane's last one, when lpi does not divide n1w)
@@ -942,9 +947,8 @@ sat_sa_kernel(const SatKernelArgs a)
 #if defined(SAT_DUP) && SAT_DUP == 2
                                 (void)*(const volatile __attribute__((address_space(3))) uint32_t *)&smap[kwu * TP + owner];   // diagnostic: map word read twice
 #endif
-                                const uint32_t qi = (uint32_t)(kwu * N1P + si);
-                                qd[u] = load_qdist(qi);
-                                qc[u] = load_qcode(qi);
+                                qd[u] = load_qdist(qoff16 + (uint32_t)(u * lpi * N1P * 16));
+                                qc[u] = load_qcode(qoff4 + (uint32_t)(u * lpi * N1P * 4));
                             }
 #pragma unroll
                             for (int u = 0; u < W; u++) v = quad_terms(qd[u], qc[u], drow, wd[u], 0u, v);
@@ -1013,9 +1017,9 @@ sat_sa_kernel(const SatKernelArgs a)
                     int sum_new = 0, sum_old = 0;
                     auto move_group = [&](int kw) {
                         const uint32_t word = smap[kw * TP + tid];
-                        const uint32_t qi = (uint32_t)(kw * N1P + ssei);      // 32-bit offset from a uniform base
-                        const float4 qd = load_qdist(qi);
-                        const uint32_t qc = load_qcode(qi);
+                        const uint32_t qi = (uint32_t)(kw * N1P + ssei);      // 32-bit offsets from uniform bases
+                        const float4 qd = load_qdist(qi << 4);
+                        const uint32_t qc = load_qcode(qi << 2);
                         sum_new = quad_terms(qd, qc, nrow, word, 0u, sum_new);
                         sum_old = quad_terms(qd, qc, orow, word, 0u, sum_old);
                     };
