@@ -91,6 +91,9 @@ def build_test_native(force=False):
     out = os.path.join(tdir, "librocrand_check.so")
     if force or _stale(out, [src, os.path.join(CSRC, "sat_sa_kernel.hpp")]):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, "-I", CSRC, "-o", out, src])
+    src2, out2 = os.path.join(tdir, "lds_residency.hip"), os.path.join(tdir, "liblds_residency.so")
+    if os.path.exists(src2) and (force or _stale(out2, [src2])):
+        _run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out2, src2])
     return out
 
 

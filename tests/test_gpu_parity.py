@@ -634,6 +634,26 @@ def test_full_size_properties():
     print(f"100k x 32-SSE: {ms:.1f} ms -> {n / ms * 1e3:.0f} scorings/s")
 
 
+# ---------------------------------------------------------------- the hardware fact the launch sizing uses
+def test_lds_is_handed_out_in_128_granules_of_1280_bytes():
+    """pick_epw (csrc/sat_capi.hip) counts resident entries per CU as 128 / ceil(bytes / 1280): the CU hands
+    out its 160 KB of LDS in 1280-byte granules.  Measured here with workgroups that count themselves
+    in and out (tests/native/lds_residency.hip): the workgroups resident on a CU drop exactly where a
+    workgroup needs one more granule or the 128 are used up.  If a driver or firmware changes this, the
+    sizing loses throughput (never correctness) and this test says why."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "native", "liblds_residency.so"))
+    lib.lds_resident_per_cu.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.lds_resident_per_cu.restype = ctypes.c_int
+    expect = {(128, 11_520): 14, (128, 11_521): 12,        # 9 granules x 14 = 126 | 10 x 12 = 120
+              (128, 12_800): 12, (128, 12_801): 11,        # 10 granules | 11 x 11 = 121
+              (128, 14_080): 11, (128, 14_081): 10,        # 11 granules | 12 x 10 = 120
+              (256, 26_880): 6, (256, 26_881): 5,          # 21 granules x 6 = 126 | 22 x 5 = 110
+              (256, 32_000): 5, (256, 32_001): 4}          # 25 granules x 5 = 125 | 26 x 4 = 104
+    got = {k: lib.lds_resident_per_cu(*k) for k in expect}
+    assert got == expect
+
+
 # ---------------------------------------------------------------- the random stream and rocRAND
 def test_philox_block_is_rocrands_block():
     """The kernel writes its Philox4x32-10 block out by hand (sat_sa_kernel.hpp, philox_block); the
