@@ -296,6 +296,8 @@ int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
 // workgroups of a multiple of 4 waves and at most 512 threads are considered: measured on the bench,
 // 6-wave workgroups do not spread evenly over the 4 SIMDs (8.5 M scorings/s against 10.6 M), and 12-wave
 // ones lose to their own start-up and drain phases what the extra residency gains (10.4 M).
+int resident_by_lds(size_t bytes) { return (int)(128 / ((bytes + 1279) / 1280)); }
+
 int pick_epw(kernel_fn fn, int threads, size_t lds_stride)
 {
     int best = 1, best_entries = 0;
@@ -306,8 +308,7 @@ int pick_epw(kernel_fn fn, int threads, size_t lds_stride)
             (void)hipGetLastError();
             return 1;
         }
-        const int granules = (int)(((size_t)k * lds_stride + 1279) / 1280);
-        const int by_lds = 128 / granules;
+        const int by_lds = resident_by_lds((size_t)k * lds_stride);
         const int entries = (by_regs < by_lds ? by_regs : by_lds) * k;
         if (entries > best_entries) { best_entries = entries; best = k; }
     }
@@ -406,7 +407,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                 const size_t lds_l = satk::lds_bytes(n1max, n1p, n2max, chains, chains << l, lsoln != 0, qlds, compact);
                 if (lds_l > kLdsLimit) break;
                 lpc_shift = l;
-                if ((int)(kLdsLimit / lds_l) * ((chains << l) / 64) >= 8) break;
+                if (resident_by_lds(lds_l) * ((chains << l) / 64) >= 8) break;
             }
             if (ctx->tune.lpc >= 0 && ctx->tune.lpc <= 2 && (chains << ctx->tune.lpc) <= 1024) lpc_shift = ctx->tune.lpc;
             // the per-wave tables grow with the lanes: re-size, backing off if that no longer fits
@@ -978,10 +979,10 @@ unsigned long long sat_stat_d2h_bytes(const sat_ctx *ctx) { return ctx ? ctx->d2
 
 const char *sat_last_launch_info(const sat_ctx *ctx) { return ctx ? ctx->last_launch_info.c_str() : ""; }
 
-void sat_debug_lds_layout(int split, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
+void sat_debug_lds_layout(int m2w, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
                           uint32_t out[11])
 {
-    const satk::LdsLayout L = satk::lds_layout(split != 0, n2, satk::map_words((n1 + 3) >> 2), n1p, chains, threads,
+    const satk::LdsLayout L = satk::lds_layout(m2w, n2, satk::map_words((n1 + 3) >> 2), n1p, chains, threads,
                                                q_in_lds != 0, compact != 0);
     const uint32_t v[11] = { L.code, L.qdist, L.qcode, L.smap, L.tmask, L.qtypes, L.leader, L.red, L.red_stride, L.items, L.total };
     for (int i = 0; i < 11; i++) out[i] = v[i];

@@ -389,10 +389,13 @@ struct LdsLayout {
     uint32_t items;       // per-wave item tables of the work compaction
     uint32_t total;
 };
-__host__ __device__ inline LdsLayout lds_layout(bool split, int n2, int words, int n1p, int chains, int threads,
+// m2w = 32-bit words of a db-side bit set in this launch's size class (1, 2 or 4); the cells are split
+// (4-byte distances + 1-byte codes) exactly when m2w > 1.
+__host__ __device__ inline LdsLayout lds_layout(int m2w, int n2, int words, int n1p, int chains, int threads,
                                                  bool q_in_lds, bool compact)
 {
     LdsLayout L;
+    const bool split = m2w > 1;
     // rows 0 .. n2-1 of the cell matrix, columns 0 .. n2: the null SSE (index n2) has a column - map bytes
     // of unmatched query SSEs point at it - but no row: a null image scores 0 and its row is never summed
     uint32_t dcells = (uint32_t)n2 * (uint32_t)(n2 + 1);
@@ -414,7 +417,7 @@ __host__ __device__ inline LdsLayout lds_layout(bool split, int n2, int words, i
     // an even word count keeps what follows 8-byte aligned
     off += (((uint32_t)words * (uint32_t)(chains + 1) + 1u) & ~1u) * 4u;
     L.tmask = off;
-    off += (split ? 16u : 4u) * 4u;                           // one word per type up to 32 db SSEs, else four
+    off += 4u * (uint32_t)m2w * 4u;                           // [4 types][m2w words]
     L.qtypes = off;
     off += ((uint32_t)n1p + 15u) & ~15u;
     off = (off + 7u) & ~7u;
@@ -436,7 +439,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
                                              bool compact)
 {
     (void)lsoln;                                              // the best maps live in global memory
-    return lds_layout(n2 > 32, n2, map_words((n1 + 3) >> 2), n1p, chains, threads, q_in_lds, compact).total;
+    return lds_layout(n2 <= 32 ? 1 : (n2 <= 64 ? 2 : 4), n2, map_words((n1 + 3) >> 2), n1p, chains, threads, q_in_lds, compact).total;
 }
 
 #ifdef SAT_EXP_PERTURB
@@ -540,7 +543,7 @@ sat_sa_kernel(const SatKernelArgs a)
     // ---- carve LDS: satk::lds_layout, the function the host sizes the workgroup with.  The cell layout
     // goes by the launch's size class, not by this entry's order (n2max > 32 <=> M2W > 1).
     constexpr bool SPLIT = M2W > 1;
-    const LdsLayout lay = lds_layout(SPLIT, n2, cmp_words, N1P, T, nthreads, QLDS, opt_compact);
+    const LdsLayout lay = lds_layout(M2W, n2, cmp_words, N1P, T, nthreads, QLDS, opt_compact);
     uint2 *Dc = reinterpret_cast<uint2 *>(lds_slot);                          // !SPLIT: 8-byte cells
     float *distL = reinterpret_cast<float *>(lds_slot);                       // SPLIT: distances ...
     uint8_t *codeL = lds_slot + lay.code;                                     // ... and code bytes
@@ -562,7 +565,7 @@ sat_sa_kernel(const SatKernelArgs a)
     uint8_t *qtypes = lds_slot + lay.qtypes;
     unsigned char *red_b = lds_slot + lay.red;
     auto red_key = [&](int w) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(red_b + (uint32_t)w * lay.red_stride); };
-    constexpr int TMS = M2W == 1 ? 1 : 4;                     // words per type of the type masks
+    constexpr int TMS = M2W;                                  // words per type of the type masks
     // explicit LDS address space: these two are written by some lanes and read by others of the
     // same wave between wavefront-scope fences, and must stay ds_* instructions
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;

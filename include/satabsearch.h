@@ -234,9 +234,10 @@ const char *sat_last_launch_info(const sat_ctx *ctx);
  * the one function both the kernel and the launch sizing use), byte offsets out[0..10] = code bytes,
  * query distances, query codes, chain maps, type masks, query types, LSOLN leader key, the waves'
  * arg-max keys, the byte stride between those keys (256: inside the item tables), item tables, total.
+ * m2w = words of a db-side bit set in the launch's size class: 1 (entries up to 32 SSEs), 2 (64) or 4.
  * Lets tests assert alignment and monotonicity without a GPU.
  */
-void sat_debug_lds_layout(int split, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
+void sat_debug_lds_layout(int m2w, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
                           uint32_t out[11]);
 
 /*

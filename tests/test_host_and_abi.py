@@ -164,8 +164,8 @@ def test_lds_carve_alignment_and_monotonicity():
     lib = _native.device_lib()
     out = (ctypes.c_uint32 * 11)()
 
-    def layout(split, n1, n1p, n2, chains, threads, qlds, compact):
-        lib.sat_debug_lds_layout(split, n1, n1p, n2, chains, threads, qlds, compact, out)
+    def layout(m2w, n1, n1p, n2, chains, threads, qlds, compact):
+        lib.sat_debug_lds_layout(m2w, n1, n1p, n2, chains, threads, qlds, compact, out)
         return list(out)
 
     classes = [(16, range(1, 17)), (32, range(17, 33)), (64, range(33, 65)), (112, range(65, 112))]
@@ -177,14 +177,14 @@ def test_lds_carve_alignment_and_monotonicity():
                     for compact in (0, 1):
                         prev_total = 0
                         for n2 in list(range(1, 112, 5)) + [32, 33, 111]:
-                            split = int(n2 > 32)
+                            m2w = 1 if n2 <= 32 else (2 if n2 <= 64 else 4)
                             code, qdist, qcode, smap, tmask, qtypes, leader, red, red_stride, items, total = layout(
-                                split, n1, n1p, n2, chains, threads, qlds, compact)
+                                m2w, n1, n1p, n2, chains, threads, qlds, compact)
                             assert leader % 8 == 0 and red % 8 == 0 and red_stride % 8 == 0, (n1, n2, chains)
                             assert qdist % 16 == 0 and smap % 4 == 0 and tmask % 4 == 0 and items % 4 == 0
                             assert code <= qdist <= qcode <= smap < tmask < qtypes < leader < red <= items <= total
                             assert tmask - smap >= 4 * ((n1 + 3) // 4) * (chains + 1)
-                            assert qtypes - tmask == (64 if split else 16) and leader - qtypes >= n1p and red - leader == 8
+                            assert qtypes - tmask == 16 * m2w and leader - qtypes >= n1p and red - leader == 8
                             waves = (threads + 63) // 64
                             if compact:        # a wave's arg-max key is the head of its own item table
                                 assert red == items and red_stride == 256 and total - items == waves * 256
@@ -192,10 +192,10 @@ def test_lds_carve_alignment_and_monotonicity():
                                 assert red_stride == 8 and items - red == 16 * 8 and total == items
                             assert red + (waves - 1) * red_stride + 8 <= total
                         # monotone in n2 within a cell layout, and in n1
-                        for split, orders in ((0, range(1, 33)), (1, range(33, 112))):
-                            totals = [layout(split, n1, n1p, n2, chains, threads, qlds, compact)[10] for n2 in orders]
+                        for m2w, orders in ((1, range(1, 33)), (2, range(33, 65)), (4, range(65, 112)), (4, range(1, 112))):
+                            totals = [layout(m2w, n1, n1p, n2, chains, threads, qlds, compact)[10] for n2 in orders]
                             assert totals == sorted(totals)
-                        totals = [layout(0, k, n1p, 20, chains, threads, qlds, compact)[10] for k in n1s]
+                        totals = [layout(1, k, n1p, 20, chains, threads, qlds, compact)[10] for k in n1s]
                         assert totals == sorted(totals)
 
 
