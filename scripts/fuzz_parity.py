@@ -11,6 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t0 = time.time()
 cases = 0
+last_note = t0
 if True:
     while time.time() - t0 < budget:
         n = int(rng.integers(3, 60))
@@ -49,6 +50,9 @@ if True:
         osc, omp, _ = oracle_lib.search(db, *q, lorder, lsoln, r, seed=77, query_ordinal=qord)
         ok = np.array_equal(sc, osc) and (not lsoln or np.array_equal(mp, omp))
         cases += 1
+        if time.time() - last_note > 45:                 # a line a minute: a silent GPU run is taken to be hung
+            print(f"  {cases} cases ok after {time.time()-t0:.0f}s", flush=True)
+            last_note = time.time()
         if not ok:
             print("MISMATCH", dict(n=n, lo=lo, hi=hi, src=src, keep=keep, lorder=lorder, lsoln=lsoln, r=r, qord=qord,
                                    env={k: os.environ.get(k) for k in ("SAT_EXP_LPC", "SAT_EXP_COMPACT", "SAT_EXP_EPW")}))
