@@ -722,19 +722,24 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
     // bucket lists; inside a bucket the LARGEST entries first (file order among equals): workgroups are
     // dispatched in list order and a larger entry runs longer, so the launch ends on its cheapest
     // workgroups instead of its dearest (real databases are sorted ascending)
-    std::vector<int32_t> lists;
-    lists.reserve(n_entries);
-    for (int b = 0; b < kNumBuckets; b++) {
-        ctx->bucket_begin[b] = (int)lists.size();
-        ctx->bucket_n2max[b] = 0;
-        const int lo = b == 0 ? 0 : kBucketMax[b - 1];
-        for (int e = 0; e < n_entries; e++)
-            if (orders[e] > lo && orders[e] <= kBucketMax[b]) {
-                lists.push_back(e);
-                if (orders[e] > ctx->bucket_n2max[b]) ctx->bucket_n2max[b] = orders[e];
+    // (a counting sort by order: two passes over the entries - seven filtered passes and a stable sort per
+    // bucket took 3 ms of an 11 ms upload of the bench shard)
+    std::vector<int32_t> lists((size_t)n_entries);
+    {
+        int count[SAT_MAXDIM + 1] = { 0 }, start[SAT_MAXDIM + 1] = { 0 };
+        for (int e = 0; e < n_entries; e++) count[orders[e]]++;
+        int pos = 0;
+        for (int b = 0; b < kNumBuckets; b++) {
+            ctx->bucket_begin[b] = pos;
+            ctx->bucket_n2max[b] = 0;
+            const int lo = b == 0 ? 0 : kBucketMax[b - 1];
+            for (int n = kBucketMax[b] < SAT_MAXDIM ? kBucketMax[b] : SAT_MAXDIM; n > lo; n--) {
+                start[n] = pos;
+                pos += count[n];
+                if (count[n] && ctx->bucket_n2max[b] == 0) ctx->bucket_n2max[b] = n;
             }
-        std::stable_sort(lists.begin() + ctx->bucket_begin[b], lists.end(),
-                         [&](int32_t x, int32_t y) { return orders[x] > orders[y]; });
+        }
+        for (int e = 0; e < n_entries; e++) lists[(size_t)start[orders[e]]++] = e;
     }
     ctx->bucket_begin[kNumBuckets] = (int)lists.size();
 
