@@ -407,7 +407,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                 const size_t lds_l = satk::lds_bytes(n1max, n1p, n2max, chains, chains << l, lsoln != 0, qlds, compact);
                 if (lds_l > kLdsLimit) break;
                 lpc_shift = l;
-                if (resident_by_lds(lds_l) * ((chains << l) / 64) >= 8) break;
+                if (resident_by_lds(lds_l) * ((chains << l) / 64) >= ctx->tune.lpc_waves) break;
             }
             if (ctx->tune.lpc >= 0 && ctx->tune.lpc <= 2 && (chains << ctx->tune.lpc) <= 1024) lpc_shift = ctx->tune.lpc;
             // the per-wave tables grow with the lanes: re-size, backing off if that no longer fits
@@ -632,6 +632,7 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         ctx->tune.upload_threads = env_int("SAT_EXP_UPLOAD_THREADS", 0);
         ctx->tune.upload_timing = env_int("SAT_EXP_UPLOAD_TIMING", 0);
         ctx->tune.epw = env_int("SAT_EXP_EPW", 0);
+        ctx->tune.lpc_waves = env_int("SAT_EXP_LPC_WAVES", 8);
         const int pad = env_int("SAT_EXP_LDS_PAD", 0);
         ctx->tune.lds_pad = pad > 0 ? (size_t)pad : 0;
         if (ctx->tune.streams != 0) {

@@ -18,6 +18,7 @@
  * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS),
  * SAT_EXP_LDS_PAD = bytes (unused LDS added per db entry: occupancy experiments),
  * SAT_EXP_EPW = 1..8 (db entries per workgroup; default: chosen per launch from the CU's LDS granules),
+ * SAT_EXP_LPC_WAVES = n (resident waves per CU at which the lanes-per-chain choice stops adding lanes, default 8),
  * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones),
  * SAT_EXP_STREAMS = 0 (queue the order buckets of a search one after the other instead of
  * concurrently on side streams), SAT_EXP_UPLOAD_THREADS = n (host threads slicing the database
