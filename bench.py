@@ -155,6 +155,20 @@ def main():
     searcher.upload(db, db_ordinal=np.arange(rank * n_local, (rank + 1) * n_local))
     upload_ms = (time.perf_counter() - t_up) * 1e3        # host -> HBM of the packed shard (synchronous copies)
     searcher.set_query(qt, qd, qtypes, 0)
+    # a single query over a freshly read shard, upload included: the copy and the first search overlapped
+    # (sat_db_upload_search: each piece of the shard is searched while the next one is copied), on a
+    # context of its own; wall time of the call, which returns when the scores are complete on the GPU
+    overlapped_ms = None
+    if world == 1:
+        with sat.Searcher(local_rank) as one_shot:
+            one_shot.set_query(qt, qd, qtypes, 0)
+            times = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                one_shot.upload_search(db, True, False, MAXSTART, db_ordinal=np.arange(n_local))
+                times.append((time.perf_counter() - t1) * 1e3)
+            overlapped_ms = float(np.median(times))
+            first_scores, _ = one_shot.results()
     # launch on torch's current stream: the RCCL gather and the timing events follow the kernel
     searcher.use_stream(torch.cuda.current_stream().cuda_stream)
     # the device score buffer is asked for AFTER a search has been queued (satabsearch.h: pointer
@@ -202,6 +216,9 @@ def main():
             assert gathered.shape[0] == total
             own, _ = searcher.results()                    # rank 0's shard, copied by the library itself
             assert np.array_equal(gathered[:n_local].cpu().numpy(), own)
+    if rank == 0 and overlapped_ms is not None:
+        own, _ = searcher.results()
+        assert np.array_equal(first_scores, own), "overlapped upload + search differs from upload, then search"
 
     if rank == 0:
         scorings = total * args.steps
@@ -252,7 +269,7 @@ def main():
             # the boundary takes host buffers: one-off H->D of the shard, and the rate a single
             # query would see with that copy included (never `value`)
             "h2d_upload_ms": upload_ms,
-            "scorings_per_sec_incl_upload_single_query": total / (elapsed / args.steps + upload_ms * 1e-3),
+            "scorings_per_sec_incl_upload_single_query_sequential": total / (elapsed / args.steps + upload_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
@@ -262,6 +279,9 @@ def main():
                          "note": "nominal bound only: 2648 B per scoring against 12 800 dependent SA steps; "
                                  "the kernel is VALU/LDS-issue bound (DESIGN.md section 4)"},
         }
+        if overlapped_ms is not None:
+            out["upload_and_search_overlapped_ms"] = overlapped_ms
+            out["scorings_per_sec_incl_upload_single_query"] = total / (overlapped_ms * 1e-3)
         if issue:
             out["binding_resource"] = issue
         if world == 1 and not args.no_cpu_baseline:

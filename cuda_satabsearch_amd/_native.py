@@ -18,7 +18,7 @@ LABELSIZE = 8
 # every symbol include/satabsearch.h declares
 ABI_SYMBOLS = (
     "sat_last_error", "sat_abi_version", "sat_device_count", "sat_ctx_create", "sat_ctx_destroy",
-    "sat_db_upload_packed", "sat_db_upload_dense", "sat_db_size", "sat_query_set", "sat_search",
+    "sat_db_upload_packed", "sat_db_upload_search", "sat_db_upload_dense", "sat_db_size", "sat_query_set", "sat_search",
     "sat_search_async", "sat_device_scores", "sat_device_ssemaps", "sat_query_order", "sat_sync",
     "sat_search_timed", "sat_use_stream", "sat_use_own_stream", "sat_results", "sat_queries_set", "sat_query_count", "sat_topk",
     "sat_topk_hits", "sat_stat_d2h_bytes", "sat_debug_lds_layout", "sat_last_launch_info",
@@ -69,6 +69,8 @@ def device_lib():
         lib.sat_ctx_destroy.restype = None
         lib.sat_db_upload_packed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]
+        lib.sat_db_upload_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.sat_db_upload_dense.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_void_p]
         lib.sat_db_size.argtypes = [C.c_void_p]

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -315,10 +316,22 @@ int pick_epw(kernel_fn fn, int threads, size_t lds_stride)
     return best;
 }
 
-int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t stream)
+// The entries a set of launches covers: indices into the resident shard grouped by order bucket.  A search
+// covers the whole shard (the context's lists); the overlapped upload (sat_db_upload_search) searches the
+// shard piece by piece, each piece with lists of its own.
+struct ListView {
+    const int32_t *d_list;       // device array the `begin` offsets index
+    const int *begin;            // [kNumBuckets + 1]
+    const int *n2max;            // [kNumBuckets] largest order per bucket, 0 = empty
+    int n;                       // entries covered = begin[kNumBuckets] - begin[0]
+};
+
+int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t stream, const ListView *piece = nullptr)
 {
     if (!ctx) return fail(SAT_EINVAL, "null context");
     if (ctx->n_entries <= 0) return fail(SAT_ESTATE, "no database uploaded");
+    const ListView whole = { ctx->d_lists, ctx->bucket_begin, ctx->bucket_n2max, ctx->n_entries };
+    const ListView &view = piece ? *piece : whole;
     if (ctx->queries.empty()) return fail(SAT_ESTATE, "no query set");
     if (maxstart < 1) return fail(SAT_EINVAL, "maxstart must be >= 1 (got %d)", maxstart);
     HIP_TRY(hipSetDevice(ctx->device));
@@ -358,16 +371,16 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
         // A small problem cannot fill the GPU: its run time is the latency of one workgroup per
         // launch, so all order buckets go into ONE launch sized for the largest entry instead of
         // one launch per bucket queued behind each other.
-        const bool one_launch = (long long)ctx->n_entries * nqc <= 4096;
+        const bool one_launch = (long long)view.n * nqc <= 4096;
         int overall_n2max = 0;
         for (int b = 0; b < kNumBuckets; b++)
-            if (ctx->bucket_n2max[b] > overall_n2max) overall_n2max = ctx->bucket_n2max[b];
+            if (view.n2max[b] > overall_n2max) overall_n2max = view.n2max[b];
         for (int b = 0; b < kNumBuckets; b++) {
-            int count = ctx->bucket_begin[b + 1] - ctx->bucket_begin[b];
-            int n2max = ctx->bucket_n2max[b];
+            int count = view.begin[b + 1] - view.begin[b];
+            int n2max = view.n2max[b];
             if (one_launch) {
                 if (b > 0) break;
-                count = ctx->n_entries;
+                count = view.n;
                 n2max = overall_n2max;
             }
             if (count == 0) continue;
@@ -428,7 +441,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             if (ctx->lds_attr_done.insert(reinterpret_cast<const void *>(fn)).second)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-            a.entry_list = ctx->d_lists + (one_launch ? 0 : ctx->bucket_begin[b]);
+            a.entry_list = view.d_list + (one_launch ? view.begin[0] : view.begin[b]);
             // entries per workgroup (see pick_epw); small launches keep one, for the most workgroups
             const size_t lds_stride = (lds + 15) & ~(size_t)15;
             int epw = 1;
@@ -557,11 +570,12 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
 
 // Upload validation: one wave per db entry reads the entry's packed triangle where the search will
 // read it and flags cells outside the kernel's domain; the lowest flagged entry index survives.
-__global__ void __launch_bounds__(256) validate_cells(int n_entries, const int32_t *orders, const int64_t *cell_off,
+// (entries e_begin .. e_end - 1: the overlapped upload checks the shard piece by piece)
+__global__ void __launch_bounds__(256) validate_cells(int e_begin, int e_end, const int32_t *orders, const int64_t *cell_off,
                                                       const uint8_t *tab, const float *dist, int32_t *first_bad)
 {
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= n_entries) return;
+    const int e = e_begin + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= e_end) return;
     const int n = orders[e];
     const int64_t base = cell_off[e];
     const int cells = n * (n + 1) / 2;
@@ -631,6 +645,7 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         ctx->tune.streams = env_int("SAT_EXP_STREAMS", -1);
         ctx->tune.upload_threads = env_int("SAT_EXP_UPLOAD_THREADS", 0);
         ctx->tune.upload_timing = env_int("SAT_EXP_UPLOAD_TIMING", 0);
+        ctx->tune.upload_pieces = env_int("SAT_EXP_UPLOAD_PIECES", 0);
         ctx->tune.epw = env_int("SAT_EXP_EPW", 0);
         ctx->tune.lpc_waves = env_int("SAT_EXP_LPC_WAVES", 8);
         const int pad = env_int("SAT_EXP_LDS_PAD", 0);
@@ -646,7 +661,7 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         if (rc_tab != SAT_OK) return rc_tab;
         // load the library's code object now (an empty launch of its smallest kernel): the ~5 ms the
         // first launch of a process pays for it belong to context creation, not to the first upload
-        hipLaunchKernelGGL(validate_cells, dim3(1), dim3(256), 0, ctx->stream, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(validate_cells, dim3(1), dim3(256), 0, ctx->stream, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return build_gumbel_tables(ctx);
@@ -689,22 +704,56 @@ void sat_ctx_destroy(sat_ctx *ctx)
     delete ctx;
 }
 
-int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
-                         const int64_t *cell_off, const uint8_t *tab_tri,
-                         const float *dist_tri, const int64_t *db_ordinal)
+// What sat_db_upload_search asks of the upload: the first search of the current query batch, queued piece
+// by piece behind the copies.
+struct FirstSearch { int lorder, lsoln, maxstart; };
+
+// Counting sort of entries e_begin .. e_end - 1 by order into `out` (appended at position `pos`): bucket after
+// bucket, inside a bucket the LARGEST entries first (file order among equals) - workgroups are dispatched in
+// list order and a larger entry runs longer, so a launch ends on its cheapest workgroups instead of its dearest
+// (real databases are sorted ascending).  begin[kNumBuckets + 1] / n2max[kNumBuckets] describe the result.
+// (two passes over the entries: seven filtered passes and a stable sort per bucket took 3 ms of an 11 ms
+// upload of the bench shard)
+static void bucket_lists(const int32_t *orders, int e_begin, int e_end, int32_t *out, int pos, int *begin, int *n2max)
+{
+    int count[SAT_MAXDIM + 1] = { 0 }, start[SAT_MAXDIM + 1] = { 0 };
+    for (int e = e_begin; e < e_end; e++) count[orders[e]]++;
+    for (int b = 0; b < kNumBuckets; b++) {
+        begin[b] = pos;
+        n2max[b] = 0;
+        const int lo = b == 0 ? 0 : kBucketMax[b - 1];
+        for (int n = kBucketMax[b] < SAT_MAXDIM ? kBucketMax[b] : SAT_MAXDIM; n > lo; n--) {
+            start[n] = pos;
+            pos += count[n];
+            if (count[n] && n2max[b] == 0) n2max[b] = n;
+        }
+    }
+    begin[kNumBuckets] = pos;
+    for (int e = e_begin; e < e_end; e++) out[(size_t)start[orders[e]]++] = e;
+}
+
+static int upload_impl(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                       const int64_t *cell_off, const uint8_t *tab_tri,
+                       const float *dist_tri, const int64_t *db_ordinal, const FirstSearch *first)
 {
     if (!ctx) return fail(SAT_EINVAL, "null context");
     if (n_entries <= 0 || !orders || !cell_off || !tab_tri || !dist_tri)
         return fail(SAT_EINVAL, "empty database or null array");
+    if (first) {
+        if (ctx->queries.empty()) return fail(SAT_ESTATE, "no query set");
+        if (first->maxstart < 1) return fail(SAT_EINVAL, "maxstart must be >= 1 (got %d)", first->maxstart);
+    }
     // header pass on the host (orders, offsets, ordinals: a few bytes per entry).  The CELLS - every
     // code byte and distance, 331 MB for the bench shard - are checked on the GPU after the copy, at
     // HBM speed (validate_cells): a host scan of them cost as much as the copy itself.
     int64_t cells_end = 0;
+    bool ascending = true;                     // entry e + 1 starts at or after the end of entry e
     for (int e = 0; e < n_entries; e++) {
         const int n = orders[e];
         if (n < 1 || n > SAT_MAXDIM)
             return fail(SAT_EINVAL, "entry %d: order %d outside 1..%d", e, n, SAT_MAXDIM);
         if (cell_off[e] < 0) return fail(SAT_EINVAL, "entry %d: negative cell offset", e);
+        if (cell_off[e] < cells_end) ascending = false;
         int64_t end = cell_off[e] + (int64_t)n * (n + 1) / 2;
         if (end > cells_end) cells_end = end;
         if (db_ordinal && (db_ordinal[e] < 0 || db_ordinal[e] > 0xFFFFFFFFll))
@@ -720,96 +769,147 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
         if (timing) { const double t = now_ms(); fprintf(stderr, "upload: %-18s %7.3f ms\n", what, t - t_mark); t_mark = t; }
     };
 
-    // bucket lists; inside a bucket the LARGEST entries first (file order among equals): workgroups are
-    // dispatched in list order and a larger entry runs longer, so the launch ends on its cheapest
-    // workgroups instead of its dearest (real databases are sorted ascending)
-    // (a counting sort by order: two passes over the entries - seven filtered passes and a stable sort per
-    // bucket took 3 ms of an 11 ms upload of the bench shard)
-    std::vector<int32_t> lists((size_t)n_entries);
-    {
-        int count[SAT_MAXDIM + 1] = { 0 }, start[SAT_MAXDIM + 1] = { 0 };
-        for (int e = 0; e < n_entries; e++) count[orders[e]]++;
-        int pos = 0;
-        for (int b = 0; b < kNumBuckets; b++) {
-            ctx->bucket_begin[b] = pos;
-            ctx->bucket_n2max[b] = 0;
-            const int lo = b == 0 ? 0 : kBucketMax[b - 1];
-            for (int n = kBucketMax[b] < SAT_MAXDIM ? kBucketMax[b] : SAT_MAXDIM; n > lo; n--) {
-                start[n] = pos;
-                pos += count[n];
-                if (count[n] && ctx->bucket_n2max[b] == 0) ctx->bucket_n2max[b] = n;
-            }
-        }
-        for (int e = 0; e < n_entries; e++) lists[(size_t)start[orders[e]]++] = e;
+    const size_t dist_bytes = (size_t)cells_end * sizeof(float), tab_bytes = (size_t)cells_end;
+    // Pieces: with a first search to overlap, the shard goes up in `npieces` runs of whole entries of about
+    // equal cell count, and every piece is checked and searched as soon as it has landed - the GPU works on
+    // piece c while the host threads copy piece c + 1 (the copies are synchronous calls out of the caller's
+    // pageable memory; the kernels run on the context's non-blocking stream).  Needs entries laid out in
+    // ascending order (a piece is then one contiguous cell range); small shards go up in one piece.
+    int npieces = 1;
+    if (first && ascending) {
+        // at least 24 MB of distances per piece (each host thread's slice of it is then still a copy of a
+        // useful size), at most 8: measured on the 331 MB bench shard, 19.4 ms for upload-then-search,
+        // 16.3 / 14.6 / 14.2 / 15.2 / 16.8 ms overlapped in 2 / 4 / 8 / 12 / 16 pieces
+        const size_t by_size = dist_bytes / ((size_t)24 << 20);
+        npieces = ctx->tune.upload_pieces > 0 ? ctx->tune.upload_pieces : (int)(by_size < 8 ? by_size : 8);
+        if (npieces > n_entries) npieces = n_entries;
+        if (npieces < 1) npieces = 1;
     }
-    ctx->bucket_begin[kNumBuckets] = (int)lists.size();
+    std::vector<int> piece_e((size_t)npieces + 1, n_entries);        // piece c = entries piece_e[c] .. piece_e[c+1]-1
+    piece_e[0] = 0;
+    for (int c = 1, e = 0; c < npieces; c++) {
+        const int64_t target = cells_end * c / npieces;
+        while (e < n_entries && cell_off[e] < target) e++;
+        piece_e[(size_t)c] = e > piece_e[(size_t)c - 1] ? e : piece_e[(size_t)c - 1];
+    }
+    auto piece_cell = [&](int c) -> int64_t { return c >= npieces || piece_e[(size_t)c] >= n_entries ? cells_end : (c == 0 ? 0 : cell_off[piece_e[(size_t)c]]); };
+
+    // bucket lists of the whole shard (every later search) and, behind them, of each piece
+    std::vector<int32_t> lists((size_t)n_entries * (npieces > 1 ? 2 : 1));
+    bucket_lists(orders, 0, n_entries, lists.data(), 0, ctx->bucket_begin, ctx->bucket_n2max);
+    std::vector<int> piece_begin((size_t)npieces * (kNumBuckets + 1)), piece_n2max((size_t)npieces * kNumBuckets);
+    if (npieces > 1) {
+        int pos = n_entries;
+        for (int c = 0; c < npieces; c++) {
+            bucket_lists(orders, piece_e[(size_t)c], piece_e[(size_t)c + 1], lists.data(), pos,
+                         &piece_begin[(size_t)c * (kNumBuckets + 1)], &piece_n2max[(size_t)c * kNumBuckets]);
+            pos += piece_e[(size_t)c + 1] - piece_e[(size_t)c];
+        }
+    }
 
     std::vector<uint32_t> ord(n_entries);
     for (int e = 0; e < n_entries; e++) ord[e] = db_ordinal ? (uint32_t)db_ordinal[e] : (uint32_t)e;
 
     lap("host lists");
-    HIP_TRY(hipMalloc(&ctx->d_orders, (size_t)n_entries * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&ctx->d_cell_off, (size_t)n_entries * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(&ctx->d_ordinal, (size_t)n_entries * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&ctx->d_lists, (size_t)n_entries * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&ctx->d_tab, (size_t)cells_end));
-    HIP_TRY(hipMalloc(&ctx->d_dist, (size_t)cells_end * sizeof(float)));
-    HIP_TRY(hipMalloc(&ctx->d_scores, (size_t)n_entries * sizeof(int32_t)));
-    lap("hipMalloc");
-    // The two big arrays go up in slices from a few host threads (each slice a synchronous copy out
-    // of the caller's pageable memory: the runtime stages it through its pinned buffers, and several
-    // copies in flight keep the link busy while one thread waits for its staging buffer)
-    {
-        const size_t dist_bytes = (size_t)cells_end * sizeof(float), tab_bytes = (size_t)cells_end;
+    int32_t *d_bad = nullptr;
+    const int32_t none = 0x7FFFFFFF;
+    // any failure below leaves the context without a database
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&ctx->d_orders, (size_t)n_entries * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&ctx->d_cell_off, (size_t)n_entries * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&ctx->d_ordinal, (size_t)n_entries * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&ctx->d_lists, lists.size() * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&ctx->d_tab, (size_t)cells_end));
+        HIP_TRY(hipMalloc(&ctx->d_dist, (size_t)cells_end * sizeof(float)));
+        HIP_TRY(hipMalloc(&ctx->d_scores, (size_t)n_entries * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&d_bad, sizeof(int32_t)));
+        lap("hipMalloc");
+        // the headers first: the piece-wise checks and searches read them
+        HIP_TRY(hipMemcpy(ctx->d_orders, orders, (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_cell_off, cell_off, (size_t)n_entries * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_ordinal, ord.data(), (size_t)n_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_lists, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(ctx->d_scores, 0, (size_t)n_entries * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(d_bad, &none, sizeof none, hipMemcpyHostToDevice));
+        lap("header copies");
+        ctx->scores_cap = (size_t)n_entries;     // what refresh_descriptors compares with: no re-allocation for one query
+        ctx->n_entries = n_entries;
+
+        // The two big arrays go up in slices from a few host threads (each slice a synchronous copy out
+        // of the caller's pageable memory: the runtime stages it through its pinned buffers, and several
+        // copies in flight keep the link busy while one thread waits for its staging buffer).  The threads
+        // walk the pieces together and count themselves off per piece; thread 0 queues the check of a
+        // complete piece and (sat_db_upload_search) its search, and goes on copying.
         unsigned hw = std::thread::hardware_concurrency();
         int nthreads = (int)(hw ? (hw < 4 ? hw : 4) : 1);
         if (ctx->tune.upload_threads > 0) nthreads = ctx->tune.upload_threads;
         if (dist_bytes < ((size_t)32 << 20)) nthreads = 1;
         std::vector<hipError_t> err((size_t)nthreads, hipSuccess);
-        auto slice = [&](int t) {
-            (void)hipSetDevice(ctx->device);
-            auto part = [&](const void *src, void *dst, size_t bytes) {
+        std::vector<std::atomic<int>> landed((size_t)npieces);
+        for (auto &x : landed) x.store(0);
+        auto copy_piece = [&](int t, int c) {
+            const size_t c0 = (size_t)piece_cell(c), c1 = (size_t)piece_cell(c + 1);
+            auto part = [&](const void *src, void *dst, size_t unit) {
+                const size_t bytes = (c1 - c0) * unit, base = c0 * unit;
                 const size_t lo = (bytes * (size_t)t / (size_t)nthreads) & ~(size_t)255;
                 const size_t hi = t + 1 == nthreads ? bytes : (bytes * (size_t)(t + 1) / (size_t)nthreads) & ~(size_t)255;
                 if (hi > lo && err[(size_t)t] == hipSuccess)
-                    err[(size_t)t] = hipMemcpy((char *)dst + lo, (const char *)src + lo, hi - lo, hipMemcpyHostToDevice);
+                    err[(size_t)t] = hipMemcpy((char *)dst + base + lo, (const char *)src + base + lo, hi - lo, hipMemcpyHostToDevice);
             };
-            part(dist_tri, ctx->d_dist, dist_bytes);
-            part(tab_tri, ctx->d_tab, tab_bytes);
+            part(dist_tri, ctx->d_dist, sizeof(float));
+            part(tab_tri, ctx->d_tab, 1);
+            landed[(size_t)c].fetch_add(1, std::memory_order_release);
+        };
+        // (the runtime takes the copies of all threads through one queue: a thread running ahead into piece
+        // c + 1 would delay the last slice of piece c, and with it the piece's search, so nobody starts a
+        // piece before the one before it is complete)
+        auto piece_complete = [&](int c) {
+            while (landed[(size_t)c].load(std::memory_order_acquire) < nthreads) std::this_thread::yield();
+        };
+        auto helper = [&](int t) {
+            (void)hipSetDevice(ctx->device);
+            for (int c = 0; c < npieces; c++) {
+                copy_piece(t, c);
+                if (c + 1 < npieces) piece_complete(c);
+            }
         };
         std::vector<std::thread> pool;
-        for (int t = 1; t < nthreads; t++) pool.emplace_back(slice, t);
-        slice(0);
+        for (int t = 1; t < nthreads; t++) pool.emplace_back(helper, t);
+        int rc = SAT_OK;
+        for (int c = 0; c < npieces; c++) {
+            copy_piece(0, c);
+            piece_complete(c);
+            if (rc != SAT_OK) continue;                      // (the helpers still finish their copies)
+            // ---- check every cell where it now lives: one wave per entry; the kernel's pair arithmetic needs
+            // tableau nibbles 0..7 (the reader produces 0..4), SSE types 0..3 and |distance| < 1e29 or non-finite.
+            // A search queued behind the check of a bad piece is memory-safe (orders and offsets were checked
+            // above; bad cells only give wrong sums) and its results are thrown away below.
+            const int e0 = piece_e[(size_t)c], e1 = piece_e[(size_t)c + 1];
+            if (e1 <= e0) continue;
+            hipLaunchKernelGGL(validate_cells, dim3((unsigned)((e1 - e0 + 3) / 4)), dim3(256), 0, ctx->stream,
+                               e0, e1, ctx->d_orders, ctx->d_cell_off, ctx->d_tab, ctx->d_dist, d_bad);
+            if (hipGetLastError() != hipSuccess) { rc = fail(SAT_EDEVICE, "launch of the cell check failed"); continue; }
+            if (first) {
+                if (npieces > 1) {
+                    const ListView piece = { ctx->d_lists, &piece_begin[(size_t)c * (kNumBuckets + 1)],
+                                             &piece_n2max[(size_t)c * kNumBuckets], e1 - e0 };
+                    rc = launch_search(ctx, first->lorder, first->lsoln, first->maxstart, ctx->stream, &piece);
+                } else {
+                    rc = launch_search(ctx, first->lorder, first->lsoln, first->maxstart, ctx->stream);
+                }
+            }
+        }
         for (auto &th : pool) th.join();
+        if (rc != SAT_OK) return rc;
         for (int t = 0; t < nthreads; t++) HIP_TRY(err[(size_t)t]);
-    }
-    lap("cell copies");
-    HIP_TRY(hipMemcpy(ctx->d_orders, orders, (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_cell_off, cell_off, (size_t)n_entries * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_ordinal, ord.data(), (size_t)n_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_lists, lists.data(), (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(ctx->d_scores, 0, (size_t)n_entries * sizeof(int32_t)));
-
-    lap("header copies");
-    // ---- check every cell where it now lives: one wave per entry; the kernel's pair arithmetic needs
-    // tableau nibbles 0..7 (the reader produces 0..4), SSE types 0..3 and |distance| < 1e29 or non-finite
-    {
-        int32_t *d_bad = nullptr;
-        HIP_TRY(hipMalloc(&d_bad, sizeof(int32_t)));
-        const int32_t none = 0x7FFFFFFF;
-        HIP_TRY(hipMemcpy(d_bad, &none, sizeof none, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(validate_cells, dim3((unsigned)((n_entries + 3) / 4)), dim3(256), 0, ctx->stream,
-                           n_entries, ctx->d_orders, ctx->d_cell_off, ctx->d_tab, ctx->d_dist, d_bad);
+        lap(first ? "cell copies, checks and the search queued" : "cell copies");
         int32_t bad = none;
-        hipError_t e1 = hipGetLastError();
-        if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);       // a non-blocking stream: the copy below does not wait for it
-        hipError_t e2 = e1 == hipSuccess ? hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost) : e1;
-        (void)hipFree(d_bad);
-        HIP_TRY(e2);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));          // a non-blocking stream: the copy below does not wait for it
+        HIP_TRY(hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost));
+        lap(first ? "search + validate on GPU" : "validate on GPU");
         if (bad != none) {
             // the earliest flagged entry is looked at again on the host, cell by cell, for the message
             const int e = bad, n = orders[e];
-            free_db(ctx);
             for (int i = 0; i < n; i++) {
                 const int64_t rowbase = cell_off[e] + (int64_t)i * (i + 1) / 2;
                 uint8_t ty = tab_tri[rowbase + i];
@@ -824,12 +924,33 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
             }
             return fail(SAT_EINVAL, "entry %d: invalid cell", e);     // not reached: the scan and the re-check agree
         }
+        return SAT_OK;
+    };
+    const int rc = body();
+    if (d_bad) (void)hipFree(d_bad);
+    if (rc != SAT_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_db(ctx);
+        return rc;
     }
-    lap("validate on GPU");
-    ctx->scores_cap = (size_t)n_entries;     // what refresh_descriptors compares with: no re-allocation for one query
-    ctx->n_entries = n_entries;
     ctx->h_orders.assign(orders, orders + n_entries);
     return SAT_OK;
+}
+
+int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                         const int64_t *cell_off, const uint8_t *tab_tri,
+                         const float *dist_tri, const int64_t *db_ordinal)
+{
+    return upload_impl(ctx, n_entries, orders, cell_off, tab_tri, dist_tri, db_ordinal, nullptr);
+}
+
+int sat_db_upload_search(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                         const int64_t *cell_off, const uint8_t *tab_tri,
+                         const float *dist_tri, const int64_t *db_ordinal,
+                         int lorder, int lsoln, int maxstart)
+{
+    const FirstSearch first = { lorder, lsoln, maxstart };
+    return upload_impl(ctx, n_entries, orders, cell_off, tab_tri, dist_tri, db_ordinal, &first);
 }
 
 int sat_db_upload_dense(sat_ctx *ctx, int n_entries, const int32_t *orders,

@@ -71,6 +71,23 @@ class Searcher:
         self.n_entries = n
         self._orders = db.orders.copy()
 
+    def upload_search(self, db: StructSet, lorder=True, lsoln=False, maxstart=DEFAULT_MAXSTART, db_ordinal=None):
+        """upload() and the first search of the query (batch) set before, overlapped: each piece of the
+        shard is searched while the next one is copied (sat_db_upload_search).  Collect with results()."""
+        n = len(db)
+        ordinal = None
+        if db_ordinal is not None:
+            ordinal = np.ascontiguousarray(db_ordinal, dtype=np.int64)
+            if ordinal.shape[0] != n:
+                raise ValueError("db_ordinal length mismatch")
+        self.n_entries = 0
+        self._check(self._lib.sat_db_upload_search(
+            self._ctx, n, db.orders.ctypes.data, db.cell_off.ctypes.data, db.tab.ctypes.data,
+            db.dist.ctypes.data, ordinal.ctypes.data if ordinal is not None else None,
+            int(bool(lorder)), int(bool(lsoln)), int(maxstart)))
+        self.n_entries = n
+        self._orders = db.orders.copy()
+
     def upload_dense(self, orders, tabs, dmats, pitch, db_ordinal=None):
         orders = np.ascontiguousarray(orders, dtype=np.int32)
         tabs = np.ascontiguousarray(tabs, dtype=np.uint8)

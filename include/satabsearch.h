@@ -22,7 +22,8 @@
  * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones),
  * SAT_EXP_STREAMS = 0 (queue the order buckets of a search one after the other instead of
  * concurrently on side streams), SAT_EXP_UPLOAD_THREADS = n (host threads slicing the database
- * copy, default 4), SAT_EXP_UPLOAD_TIMING = 1 (per-phase upload times on stderr).
+ * copy, default 4), SAT_EXP_UPLOAD_TIMING = 1 (per-phase upload times on stderr),
+ * SAT_EXP_UPLOAD_PIECES = n (pieces of the overlapped upload + search, default by size, at most 8).
  * There is no CPU fallback: without a usable HIP device sat_ctx_create() fails with
  * SAT_ENODEVICE.
  */
@@ -89,6 +90,23 @@ void sat_ctx_destroy(sat_ctx *ctx);
 int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
                          const int64_t *cell_off, const uint8_t *tab_tri,
                          const float *dist_tri, const int64_t *db_ordinal);
+
+/*
+ * Upload a shard AND run the first search of the current query (or query batch) over it, overlapped:
+ * the shard goes up in a few pieces of whole entries, and each piece is checked and searched on the GPU
+ * while the host copies the next one - a single query over a freshly read database then costs about
+ * max(copy, search) instead of their sum (the reference copies the whole database, H.cu:924-967, then
+ * launches, H.cu:1036).  Arguments as sat_db_upload_packed + sat_search_async; the query must be set
+ * before.  On return the shard is resident and validated as after sat_db_upload_packed, and the search
+ * has completed: collect with sat_results / sat_topk_hits / sat_device_scores.  Results are those of
+ * sat_db_upload_packed followed by sat_search, bit for bit.  Entries laid out in ascending cell order
+ * (as every reader here produces them) are needed for the overlap; otherwise, and for small shards,
+ * the two steps simply run one after the other.
+ */
+int sat_db_upload_search(sat_ctx *ctx, int n_entries, const int32_t *orders,
+                         const int64_t *cell_off, const uint8_t *tab_tri,
+                         const float *dist_tri, const int64_t *db_ordinal,
+                         int lorder, int lsoln, int maxstart);
 
 /*
  * Same, from the reference's dense host layout: entry e occupies

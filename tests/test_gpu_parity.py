@@ -570,6 +570,74 @@ def test_device_score_buffer_is_the_one_the_search_fills():
             assert np.array_equal(dev, host)
 
 
+@pytest.mark.parametrize("pieces", [0, 1, 3, 8])
+def test_overlapped_upload_and_first_search(monkeypatch, pieces):
+    """sat_db_upload_search = sat_db_upload_packed + sat_search, bit for bit, whatever the number of
+    pieces the shard goes up in (0: the library's own choice - one piece at this size): a size-sorted
+    mixed database (several order buckets per piece, pieces cut inside a bucket), a query batch of two
+    size classes, scores and solution maps; the context then serves later searches as after a plain
+    upload; a sample is checked against the oracle."""
+    if pieces:
+        monkeypatch.setenv("SAT_EXP_UPLOAD_PIECES", str(pieces))
+    db = sat.synth.make_db(6000, 4, 70, seed=21, sort=True)
+    queries = [sat.synth.make_query(12, seed=5), sat.synth.make_query(40, seed=6)]
+    ordinal = np.arange(len(db)) + 1000
+    with sat.Searcher(0) as a, sat.Searcher(0) as b:
+        a.upload(db, db_ordinal=ordinal)
+        a.set_queries(queries, 3)
+        want, want_maps, _ = a.search(True, True, 64)
+        b.set_queries(queries, 3)
+        b.upload_search(db, True, True, 64, db_ordinal=ordinal)
+        got, got_maps = b.results(lsoln=True)
+        assert np.array_equal(got, want) and np.array_equal(got_maps, want_maps)
+        # the resident shard is a normal one: other options, another search
+        want2, _, _ = a.search(False, False, 64)
+        got2, _, _ = b.search(False, False, 64)
+        assert np.array_equal(got2, want2)
+    sample = np.random.default_rng(1).choice(len(db), 24, replace=False)
+    qt, qd, qtypes = queries[0]
+    ref, ref_maps, _ = oracle_lib.search(db, qt, qd, qtypes, True, True, 64, entries=sample, query_ordinal=3,
+                                         db_ordinal=ordinal)
+    assert np.array_equal(got[0][sample], ref)
+    assert np.array_equal(got_maps[0][sample], ref_maps)
+
+
+def test_overlapped_upload_rejects_what_the_plain_upload_rejects(monkeypatch):
+    """A bad cell in a late piece fails the whole call (the searches queued before it are thrown away)
+    and leaves the context without a database; entries not in ascending cell order take the
+    one-piece path and give the same results."""
+    monkeypatch.setenv("SAT_EXP_UPLOAD_PIECES", "4")
+    db = sat.synth.make_db(4000, 6, 20, seed=8)
+    q = sat.synth.make_query(10, seed=2)
+    tri = lambda e, i, j: int(db.cell_off[e]) + i * (i + 1) // 2 + j
+    with sat.Searcher(0) as s:
+        with pytest.raises(sat.SatError, match="no query"):
+            s.upload_search(db, True, False, 64)
+        s.set_query(*q, 0)
+        tab = db.tab.copy()
+        tab[tri(3900, 3, 1)] = 0x99
+        with pytest.raises(sat.SatError, match="entry 3900: tableau code"):
+            s.upload_search(sat.StructSet(db.orders, db.names, db.cell_off, tab, db.dist), True, False, 64)
+        with pytest.raises(sat.SatError, match="no database"):
+            s.search()
+        with pytest.raises(sat.SatError, match="maxstart"):
+            s.upload_search(db, True, False, 0)
+        s.upload_search(db, True, False, 64)
+        want, _ = s.results()
+        # the same entries stored back to front: offsets descend, one piece
+        order = np.arange(len(db))[::-1]
+        cells = db.orders.astype(np.int64) * (db.orders + 1) // 2
+        off = np.zeros(len(db), np.int64)
+        off[order] = np.concatenate(([0], np.cumsum(cells[order])[:-1]))
+        tab2 = np.empty_like(db.tab); dist2 = np.empty_like(db.dist)
+        for e in range(len(db)):
+            tab2[off[e]:off[e] + cells[e]] = db.tab[db.cell_off[e]:db.cell_off[e] + cells[e]]
+            dist2[off[e]:off[e] + cells[e]] = db.dist[db.cell_off[e]:db.cell_off[e] + cells[e]]
+        s.upload_search(sat.StructSet(db.orders, db.names, off, tab2, dist2), True, False, 64)
+        got, _ = s.results()
+        assert np.array_equal(got, want)
+
+
 # ---------------------------------------------------------------- reference -c stream (T3)
 def test_statistically_consistent_with_reference_host_output(searcher, small_db, golden_dir):
     """The reference's `-c` run draws from ONE sequential drand48 stream, which no parallel run can
