@@ -266,6 +266,7 @@ int refresh_descriptors(sat_ctx *ctx, bool lsoln, hipStream_t stream)
             d.qdist = reinterpret_cast<const float4 *>(ctx->d_qblob + q.blob_off);
             d.qcode = reinterpret_cast<const uint32_t *>(ctx->d_qblob + q.blob_off + groups * 16);
             d.qtypes = ctx->d_qblob + q.blob_off + groups * 20;
+            d.qpair = reinterpret_cast<const uint2 *>(ctx->d_qblob + q.blob_off + ((groups * 20 + (size_t)q.n1p + 15) & ~(size_t)15));
             d.n1 = q.n1;
             d.pad_ = 0;
             d.seed_q = ctx->seed + ((uint64_t)q.ordinal << 32);
@@ -1004,7 +1005,8 @@ int sat_queries_set(sat_ctx *ctx, int n_queries, const int32_t *n1s, const uint8
         q.blob_off = blob_bytes;
         q.ssemap_off = 0;
         const size_t groups = (size_t)q.n1p / 4 * q.n1p;
-        blob_bytes += (groups * 20 + (size_t)q.n1p + 15) & ~(size_t)15;
+        // grouped cells (16 + 4 bytes per group and column), SSE types, then the dense pair cells of the full score
+        blob_bytes += ((groups * 20 + (size_t)q.n1p + 15) & ~(size_t)15) + (size_t)q.n1p * q.n1p * 8;
     }
     // grouped, transposed query: group kw, column i holds dmat1[i][4kw..4kw+3] and the four code
     // bytes tab1[i][4kw..4kw+3]; diagonal, padding and non-finite distances get the sentinel
@@ -1019,6 +1021,21 @@ int sat_queries_set(sat_ctx *ctx, int n_queries, const int32_t *n1s, const uint8
         float4 *qdist = reinterpret_cast<float4 *>(blob.data() + q.blob_off);
         uint32_t *qcode = reinterpret_cast<uint32_t *>(blob.data() + q.blob_off + (size_t)groups * n1p * 16);
         uint8_t *qtypes = blob.data() + q.blob_off + (size_t)groups * n1p * 20;
+        // dense [i][k] cells {distance, code byte}: the same values as the grouped arrays, for the pair-by-pair
+        // full score of an initial map
+        uint32_t *qpair = reinterpret_cast<uint32_t *>(blob.data() + q.blob_off + (((size_t)groups * n1p * 20 + (size_t)n1p + 15) & ~(size_t)15));
+        for (int i = 0; i < n1p; i++)
+            for (int k = 0; k < n1p; k++) {
+                float d = SAT_K_QSENT;
+                uint32_t code = 0;
+                if (k < n1 && i < n1 && k != i) {
+                    const float v = qdmat[(size_t)i * pitch + k];
+                    if (std::isfinite(v)) d = v;                  // (range and nibbles are checked below)
+                    code = qtab[(size_t)i * pitch + k];
+                }
+                memcpy(&qpair[((size_t)i * n1p + k) * 2], &d, sizeof d);
+                qpair[((size_t)i * n1p + k) * 2 + 1] = code;
+            }
         for (int i = 0; i < n1; i++) {
             if (types[i] > 3)
                 return fail(SAT_EINVAL, "query %d: SSE %d has type code %u (0..3 expected)", qi, i, types[i]);

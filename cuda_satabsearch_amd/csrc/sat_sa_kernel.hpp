@@ -91,6 +91,9 @@
 #include <stdint.h>
 
 #define SAT_K_MAXITER 100
+#ifndef SAT_FS_UNROLL
+#define SAT_FS_UNROLL 2               // pairs per lane and round of the full score of an initial map
+#endif
 #define SAT_K_STEP_BLOCK0 32          // Philox block of SA step 0 (oracle/sa_oracle.h)
 #define SAT_K_EPS 1.1e-7              // K.cu:67
 #define SAT_K_NO_SCORE (-99999)       // K.cu:1009
@@ -103,6 +106,7 @@ struct SatQuery {
     const float4   *qdist;        // [N1P/4][N1P] distances of 4 consecutive query SSEs (transposed)
     const uint32_t *qcode;        // [N1P/4][N1P] their 4 code bytes
     const uint8_t  *qtypes;       // [N1P]
+    const uint2    *qpair;        // [N1P][N1P] dense cells {distance, code byte} for the full score of an initial map
     int32_t         n1;
     uint32_t        pad_;
     uint64_t        seed_q;       // seed + (query ordinal << 32)
@@ -188,6 +192,24 @@ template <int W> __device__ __forceinline__ int bits_count(const Bits<W> &b)
 #pragma unroll
     for (int i = 0; i < W; i++) c += __popc(b.w[i]);
     return c;
+}
+template <int W> __device__ __forceinline__ bool bits_any(const Bits<W> &b)
+{
+    uint32_t o = 0u;
+#pragma unroll
+    for (int i = 0; i < W; i++) o |= b.w[i];
+    return o != 0u;
+}
+// clears the lowest set bit (no-op on an empty set)
+template <int W> __device__ __forceinline__ void bits_drop_lowest(Bits<W> &b)
+{
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const bool here = !done && b.w[i] != 0u;
+        b.w[i] = here ? b.w[i] & (b.w[i] - 1u) : b.w[i];
+        done = done || here;
+    }
 }
 template <int W> __device__ __forceinline__ int bits_lowest(const Bits<W> &b)   // -1 if empty
 {
@@ -298,6 +320,18 @@ __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, co
     sel |= force;
     const uint32_t terms = __builtin_amdgcn_perm(0u, 0xFE010102u, sel);   // {2, 1, 1, -2 | 0, 0, 0, 0}
     return __builtin_amdgcn_sdot4((int)terms, 0x01010101, acc, false);
+}
+
+// One pair score (the full score of an initial map walks the matched pairs one by one): query cell
+// {distance, code byte}, db cell likewise; same arithmetic as one byte lane of quad_terms.
+__device__ __forceinline__ int pair_term(const uint32_t qd_bits, const uint32_t qc, const uint32_t dd_bits, const uint32_t dc)
+{
+    const float t = 4.0f - fabsf(__uint_as_float(qd_bits) - __uint_as_float(dd_bits));   // sign bit: more than 4 A apart
+    const uint32_t z = ((qc ^ dc) + 0x77u) & 0x88u;                      // bit 3: low nibbles differ, bit 7: high
+    uint32_t sel = __builtin_amdgcn_bitop3_b32(z >> 3, z >> 6, 0x3u, 0xA8);                  // (a | b) & c
+    sel = __builtin_amdgcn_bitop3_b32(__float_as_uint(t) >> 29, 0x4u, sel, 0xEA);             // (a & b) | c
+    const uint32_t terms = __builtin_amdgcn_perm(0u, 0xFE010102u, sel);  // byte 0 = {2, 1, 1, -2 | 0, 0, 0, 0}[sel]
+    return (int)(int8_t)(terms & 0xFFu);
 }
 
 // ---------------------------------------------------------------- random streams
@@ -748,8 +782,89 @@ sat_sa_kernel(const SatKernelArgs a)
             }
         }
 
-        // ---- full score of the initial map (tmscord, K.cu:396-440): pairs i < k
+        // ---- full score of the initial map (tmscord, K.cu:396-440): pairs i < k, both matched
         int score = 0;
+#ifdef SAT_FULLSCORE_ROWS
+        constexpr bool FS_PAIRS = false;                   // diagnostic builds: the rows-in-step form everywhere
+#else
+        constexpr bool FS_PAIRS = N1P > 16;
+#endif
+        if constexpr (FS_PAIRS) {
+            // Every lane walks the matched pairs of ITS chain (set bits of `mapped`: i ascending, k above i)
+            // and the wave loops until its last lane is done.  An initial map matches ~8 query SSEs whatever
+            // the query's size, so this is ~30-90 single pair evaluations per restart where walking the rows
+            // in step for all lanes costs n1w * n1 / 2 packed ones: 136 for a 32-SSE query, 1313 for 101 SSEs
+            // (half the run time of the 101-SSE query class before this loop).  Measured against the rows-in-step
+            // form below: 101-SSE query x entries of 8..96 SSEs 1.66 -> 2.1 M scorings/s, BASELINE configs[4]
+            // 1.60 -> 2.0 M, configs[2] 310 -> 443 k, 32-SSE query x entries of 8..32 SSEs +7 %, x 32-SSE
+            // entries +-0; queries of up to 16 SSEs keep the rows in step (at most 32 packed evaluations: 1.5 %
+            // faster there).
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(1))) u32x2_t *gptr_u2;
+            const gptr_c qpairG = (gptr_c)(uintptr_t)Q.qpair;
+            // thinit's maps are order preserving whatever LORDER says (K.cu:588-648), so the c-th matched query
+            // SSE has the c-th occupied db SSE as its image: with a one-word db set the two bit sets are popped
+            // in step and the map bytes are never read (with more words the byte read is cheaper than the pop)
+            constexpr bool POP_IMAGES = M2W == 1;
+            Bits<M1W> ri = mapped;
+            Bits<M2W> rj = occ;
+            // pops the lowest set bit: its position (0 when the set is empty) and whether there was one
+            auto pop = [](auto &b, bool &valid) -> int {
+                constexpr int W = sizeof(b.w) / sizeof(b.w[0]);
+                valid = bits_any<W>(b);
+                const int pos = max(bits_lowest<W>(b), 0);
+                bits_drop_lowest<W>(b);
+                return pos;
+            };
+            while (__builtin_amdgcn_ballot_w64(bits_any<M1W>(ri)) != 0ull) {
+                bool ai, aj;
+                const int i = pop(ri, ai);
+                int ji;                                                    // (a lane that is done walks row 0, sums nothing)
+                if constexpr (POP_IMAGES) ji = pop(rj, aj);
+                else { ji = smap_b[map_byte_addr(i)]; ji = ai ? ji : 0; }
+                const DbRow<SPLIT> drow = db_row(ji);
+                const uint32_t qrow = (uint32_t)__mul24(i, N1P * 8);
+                Bits<M1W> rk = ri;                                         // the matched SSEs above i ...
+                Bits<M2W> rl = rj;                                         // ... and their images
+                int rowsum = 0;
+                // SAT_FS_UNROLL pairs per lane and round, their loads in flight together; the lanes that share
+                // a chain take turns at the SSEs (all pop the same sequence, lane `part` keeps every lpc-th)
+                while (__builtin_amdgcn_ballot_w64(bits_any<M1W>(rk)) != 0ull) {
+                    int ll[SAT_FS_UNROLL];
+                    bool vv[SAT_FS_UNROLL];
+                    u32x2_t qcell[SAT_FS_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SAT_FS_UNROLL; u++) {
+                        int ku = 0;
+                        ll[u] = 0;
+                        vv[u] = false;
+                        for (int p = 0; p < lpc; p++) {
+                            bool v, vl;
+                            const int k = pop(rk, v);
+                            ku = p == part ? k : ku;
+                            vv[u] = p == part ? v : vv[u];
+                            if constexpr (POP_IMAGES) {
+                                const int l = pop(rl, vl);
+                                ll[u] = p == part ? l : ll[u];
+                            }
+                        }
+                        // (none left: SSE 0's image, possibly the null column - it exists, and the term is dropped)
+                        if constexpr (!POP_IMAGES) ll[u] = smap_b[map_byte_addr(ku)];
+                        qcell[u] = *(gptr_u2)(qpairG + (qrow + ((uint32_t)ku << 3)));
+                    }
+#pragma unroll
+                    for (int u = 0; u < SAT_FS_UNROLL; u++) {
+                        uint32_t dd, dc;
+                        if constexpr (SPLIT) { dd = __float_as_uint(drow.dist[ll[u]]); dc = drow.code[ll[u]]; }
+                        else { const uint2 c = drow.cells[ll[u]]; dd = c.x; dc = c.y; }
+                        const int term = pair_term(qcell[u].x, qcell[u].y, dd, dc);
+                        rowsum += vv[u] ? term : 0;
+                    }
+                }
+                score += rowsum;
+            }
+        } else {
+        // rows in step: every lane walks all n1 rows of its chain, the wave reads the query cells with scalar loads
         for (int i = 0; i < n1 - 1; i++) {
             // an unmatched SSE has no row in LDS: its lane walks row 0 and drops the sum
             const int j = smap_b[map_byte_addr(i)];
@@ -775,6 +890,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 for (int kw = ((i + 1) >> 2) + part; kw < n1w; kw += lpc) row_group(kw);
             }
             score += jreal ? rowsum : 0;
+        }
         }
         if (lpc >= 2) score += __shfl_xor(score, 1, 64);
         if (lpc == 4) score += __shfl_xor(score, 2, 64);
