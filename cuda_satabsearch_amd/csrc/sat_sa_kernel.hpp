@@ -168,12 +168,13 @@ template <int W> __device__ __forceinline__ Bits<W> bits_below(int pos)
         b.w[0] = (0xFFFFFFFFu >> h) >> (s - h);
         return b;
     }
+    // several words: the word that holds `pos` gets the bits below it, the words under it are full, the rest
+    // empty (pos < 0: no word is under or at it; pos >= 32 W: every word is under it) - two compares and two
+    // selects per word where a clamped 64-bit shift per word cost twice that
+    const int wi = pos >> 5;                                   // arithmetic shift: negative for pos < 0
+    const uint32_t part = (1u << (pos & 31)) - 1u;
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-        int rel = pos - 32 * i;
-        uint32_t part = (uint32_t)((1ull << (rel < 0 ? 0 : (rel > 32 ? 32 : rel))) - 1ull);
-        b.w[i] = part;
-    }
+    for (int i = 0; i < W; i++) b.w[i] = i < wi ? 0xFFFFFFFFu : (i == wi ? part : 0u);
     return b;
 }
 template <int W> __device__ __forceinline__ void bits_set(Bits<W> &b, int pos)
@@ -248,17 +249,22 @@ __device__ __forceinline__ int word_select(uint32_t v, int r)
 }
 template <int W> __device__ __forceinline__ int bits_select(const Bits<W> &b, int r)
 {
-    int pos = 0;
+    // the word that holds the r-th bit and the rank inside it first (popcounts), then ONE rank select
+    uint32_t word = b.w[0];
+    int base = 0, rr = r;
     bool found = false;
 #pragma unroll
     for (int i = 0; i < W; i++) {
-        int c = __popc(b.w[i]);
-        bool here = !found && r < c;
-        pos = here ? 32 * i + word_select(b.w[i], r) : pos;
+        const int c = __popc(b.w[i]);
+        const bool here = !found && r < c;
+        word = here ? b.w[i] : word;
+        base = here ? 32 * i : base;
+        rr = here ? r : rr;
         found = found || here;
         r -= c;
     }
-    return pos;
+    // (r beyond the set: callers never ask; an empty word would select position 31 of nothing)
+    return found ? base + word_select(word, rr) : 0;
 }
 
 // ---------------------------------------------------------------- pair scores
@@ -1174,32 +1180,32 @@ sat_sa_kernel(const SatKernelArgs a)
             if (accept) smap_b[map_byte_addr(ssei)] = (uint8_t)newj;
             score = accept ? newscore : score;
             {
-                Bits<M2W> occ2 = occ;
-                Bits<M1W> mapped2 = mapped;
+                // an accepted move toggles the old image's bit (set) and the new image's bit (clear) of `occ`, and
+                // the moved SSE's bit of `mapped` when it changes between matched and unmatched; the accept
+                // decision is folded into the bits, the word index picks the word
+                const bool oreal_ = oldj != NULLJ;
                 if constexpr (M2W == 1) {
                     // bit n2 (the null SSE) must not be touched; n2 may be 32: mask by comparison.
-                    // The accept decision is folded into the masks (scalar AND of lane masks).
-                    const uint32_t oldbit = (accept && oldj != NULLJ) ? (1u << (oldj & 31)) : 0u;
+                    const uint32_t oldbit = (accept && oreal_) ? (1u << (oldj & 31)) : 0u;
                     const uint32_t newbit = (accept && nreal) ? (1u << (newj & 31)) : 0u;
                     occ.w[0] = (occ.w[0] & ~oldbit) | newbit;
-                    occ2 = occ;
                 } else {
-                    if (oldj != NULLJ) bits_clear<M2W>(occ2, oldj);
-                    if (newj != NULLJ) bits_set<M2W>(occ2, newj);
+                    const uint32_t oldbit = (accept && oreal_) ? (1u << (oldj & 31)) : 0u;
+                    const uint32_t newbit = (accept && nreal) ? (1u << (newj & 31)) : 0u;
+                    const int ow = oldj >> 5, nw = newj >> 5;
+#pragma unroll
+                    for (int w = 0; w < M2W; w++) occ.w[w] ^= (ow == w ? oldbit : 0u) ^ (nw == w ? newbit : 0u);
                 }
                 if constexpr (M1W == 1) {
                     const uint32_t ibit = 1u << ssei;
                     const uint32_t setbit = (accept && nreal) ? ibit : 0u, clrbit = (accept && !nreal) ? ibit : 0u;
                     mapped.w[0] = (mapped.w[0] & ~clrbit) | setbit;
-                    mapped2 = mapped;
                 } else {
-                    if (newj != NULLJ) bits_set<M1W>(mapped2, ssei);
-                    else bits_clear<M1W>(mapped2, ssei);
+                    const uint32_t ibit = (accept && oreal_ != nreal) ? (1u << (ssei & 31)) : 0u;
+                    const int iw = ssei >> 5;
+#pragma unroll
+                    for (int w = 0; w < M1W; w++) mapped.w[w] ^= iw == w ? ibit : 0u;
                 }
-#pragma unroll
-                for (int w = 0; w < M2W; w++) occ.w[w] = accept ? occ2.w[w] : occ.w[w];
-#pragma unroll
-                for (int w = 0; w < M1W; w++) mapped.w[w] = accept ? mapped2.w[w] : mapped.w[w];
             }
             SAT_PHASE(5);                 // Metropolis + state update
         }
