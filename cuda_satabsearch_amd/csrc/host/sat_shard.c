@@ -2,14 +2,15 @@
 #include <stdlib.h>
 #include "sat_shard.h"
 
-/* ns per scoring, 32-SSE query, r = 128, one MI355X (scripts/cost_sweep.py, round 2) */
+/* ns per scoring, 32-SSE query, r = 128, one MI355X (scripts/cost_sweep.py at the end of round 2:
+ * profiles/r02n_cost_by_order.txt) */
 static const struct { int order; double ns; } k_cost[] = {
-    { 4, 56.2 }, { 8, 64.0 }, { 12, 73.9 }, { 16, 81.4 }, { 20, 87.5 }, { 24, 90.7 }, { 28, 94.5 }, { 32, 101.7 },
-    { 40, 144.6 }, { 48, 169.0 }, { 56, 198.3 }, { 64, 221.3 }, { 72, 279.6 }, { 80, 330.7 }, { 88, 391.8 },
-    { 96, 415.0 }, { 104, 543.7 }, { 111, 576.7 },
+    { 4, 44.5 }, { 8, 53.4 }, { 12, 62.7 }, { 16, 70.9 }, { 20, 78.4 }, { 24, 82.7 }, { 28, 87.8 }, { 32, 94.1 },
+    { 40, 122.9 }, { 48, 151.7 }, { 56, 185.0 }, { 64, 206.9 }, { 72, 258.4 }, { 80, 305.4 }, { 88, 347.5 },
+    { 96, 364.9 }, { 104, 470.1 }, { 111, 508.1 },
 };
 #define K_COST_N ((int)(sizeof(k_cost) / sizeof(k_cost[0])))
-#define K_COST_UNIT 101.7
+#define K_COST_UNIT 94.1
 
 double sat_entry_cost(int order)
 {
