@@ -101,7 +101,10 @@ int sat_db_upload_packed(sat_ctx *ctx, int n_entries, const int32_t *orders,
  * has completed: collect with sat_results / sat_topk_hits / sat_device_scores.  Results are those of
  * sat_db_upload_packed followed by sat_search, bit for bit.  Entries laid out in ascending cell order
  * (as every reader here produces them) are needed for the overlap; otherwise, and for small shards,
- * the two steps simply run one after the other.
+ * the two steps simply run one after the other.  The copies are synchronous calls (the caller's buffers
+ * may be pageable), so the overlap also needs the search on a stream they do not wait for: the context's
+ * own (non-blocking) stream, or a non-blocking stream given to sat_use_stream; on the device's default
+ * stream the pieces are copied and searched in turn - same results, no gain.
  */
 int sat_db_upload_search(sat_ctx *ctx, int n_entries, const int32_t *orders,
                          const int64_t *cell_off, const uint8_t *tab_tri,
