@@ -112,7 +112,7 @@ def cpu_baseline_all_cores(db, q, seconds=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)      # 3.4 s of searches at N = 1
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--entries", type=int, default=PER_GPU_ENTRIES, help="db entries per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -795,7 +795,19 @@ sat_sa_kernel(const SatKernelArgs a)
 #else
         constexpr bool FS_PAIRS = N1P > 16;
 #endif
+        // The pair walk below costs the wave what its busiest lane costs, m (m - 1) / 2 single pairs for m matched
+        // SSEs (~27 instructions each), the rows-in-step form n1w * n1 / 2 packed evaluations (~31 each) whatever
+        // the maps hold: a wave whose densest initial map would make the walk the dearer of the two takes the rows
+        // (all-hit databases, where thinit matches 16+ of 32 SSEs: 5.7 -> 6.6 M scorings/s on scripts/exp/
+        // dense_hits.py, its all-miss leg 7.6 -> 8.3 M).  With sets of several words a pop costs more, but pricing
+        // the pair at 60 there sent the 101-SSE-query launches to the rows too early (-4 %): one price for all.
+        bool walk_pairs = FS_PAIRS;
         if constexpr (FS_PAIRS) {
+            constexpr int PAIR_COST = 27;
+            const int m = bits_count<M1W>(mapped);
+            walk_pairs = __builtin_amdgcn_ballot_w64(__mul24(__mul24(m, m - 1), PAIR_COST) > __mul24(__mul24(n1w, n1), 31)) == 0ull;
+        }
+        if (walk_pairs) {
             // Every lane walks the matched pairs of ITS chain (set bits of `mapped`: i ascending, k above i)
             // and the wave loops until its last lane is done.  An initial map matches ~8 query SSEs whatever
             // the query's size, so this is ~30-90 single pair evaluations per restart where walking the rows
