@@ -756,7 +756,13 @@ sat_sa_kernel(const SatKernelArgs a)
         Bits<M1W> mapped = bits_zero<M1W>();
         Bits<M2W> occ = bits_zero<M2W>();
         {
-            for (int w = 0; w < cmp_words; w++) smap[w * TP + tid] = nullword;
+            {
+                // (the word addresses are formed again every restart: kept, they are loop invariants that sit in
+                // registers through the step loop - one of them ended up in scratch)
+                int wa = tid;
+                asm volatile("" : "+v"(wa));
+                for (int w = 0; w < cmp_words; w++, wa += TP) smap[wa] = nullword;
+            }
             int j = 0;
             bool stopped = false;
             for (int i0 = 0; i0 < n1; i0 += 4) {
