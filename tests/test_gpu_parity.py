@@ -398,6 +398,29 @@ def test_distance_threshold_boundary(searcher):
     assert len(set(scores.tolist())) > 1
 
 
+@pytest.mark.parametrize("lorder", [True, False])
+def test_dense_initial_maps_take_the_rows_form(searcher, lorder):
+    """The full score of an initial map walks matched pairs, or - when the densest map of a wave would
+    make that the dearer form - the rows in step (sat_sa_kernel.hpp, `walk_pairs`): an all-hit database
+    (every entry the query's source structure, thinit matches half its SSEs) sends waves to the rows,
+    a database of small strangers to the pair walk, and a mix of the two has both kinds of wave in one
+    launch.  32-SSE query class (one-word sets) and a 40-SSE query (two-word query set); bit-exact
+    against the oracle either way."""
+    for n1, seed in ((32, 5), (40, 6)):
+        base = sat.synth.make_db(1, n1, n1, seed=seed)
+        t, d = base.dense(0)
+        strangers = sat.synth.make_db(24, 6, 14, seed=seed + 10)
+        orders = [n1] * 24 + [int(o) for o in strangers.orders]
+        tabs = [t] * 24 + [strangers.dense(i)[0] for i in range(24)]
+        dmats = [d] * 24 + [strangers.dense(i)[1] for i in range(24)]
+        pick = np.random.default_rng(seed).permutation(48)
+        db = sat.StructSet.from_dense([orders[i] for i in pick], [tabs[i] for i in pick], [dmats[i] for i in pick])
+        searcher.upload(db)
+        q = sat.synth.planted_query(base, 0, keep=1.0, jitter=0.5)
+        scores, _ = check(searcher, db, q, lorder, True, 128)
+        assert scores.max() > 4 * n1            # the hits are hits
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_randomized_structures(searcher, seed):
     """Random structures over the reader's whole alphabet (all 25 code combinations incl.
