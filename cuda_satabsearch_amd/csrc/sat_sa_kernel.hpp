@@ -1022,6 +1022,13 @@ sat_sa_kernel(const SatKernelArgs a)
                 // the lowest set bit `pick` times, looping while any lane of the wave still has to
                 uint32_t c = cand.w[0];
                 int left = pick;
+                {
+                    // the first strip without the wave-level test (a ballot, a scalar branch and its wait per trip of
+                    // the loop below; most waves need one or two strips): 32-SSE bench shape +1.5 %
+                    const uint32_t go = left > 0 ? 1u : 0u;
+                    c &= c - go;
+                    left -= (int)go;
+                }
                 while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
                     const uint32_t go = left > 0 ? 1u : 0u;
                     c &= c - go;                                   // c & (c - 1) clears the lowest set bit
