@@ -423,6 +423,7 @@ struct LdsLayout {
     uint32_t smap;        // chain maps, word-interleaved [word][chain], row stride chains + 1
     uint32_t tmask;       // [4 types][4 words] db SSEs of a type
     uint32_t qtypes;      // query SSE types
+    uint32_t qmask;       // one-word db sets only: per query SSE the mask of the db SSEs of its type (tmask[qtypes[i]])
     uint32_t leader;      // the LSOLN leader key (64-bit)
     uint32_t red;         // the waves' arg-max keys (64-bit), red_stride bytes apart
     uint32_t red_stride;
@@ -460,6 +461,8 @@ __host__ __device__ inline LdsLayout lds_layout(int m2w, int n2, int words, int 
     off += 4u * (uint32_t)m2w * 4u;                           // [4 types][m2w words]
     L.qtypes = off;
     off += ((uint32_t)n1p + 15u) & ~15u;
+    L.qmask = off;
+    if (m2w == 1) off += (uint32_t)n1p * 4u;
     off = (off + 7u) & ~7u;
     L.leader = off;
     off += 8u;
@@ -603,6 +606,9 @@ sat_sa_kernel(const SatKernelArgs a)
     // best maps: word w of chain c at w*T + c of this workgroup's slab (global memory)
     uint32_t *bmap = lsoln ? a.bmap_slabs + ((size_t)blockIdx.y * gridDim.x * a.epw + list_pos) * a.bmap_slab_words : nullptr;
     uint8_t *qtypes = lds_slot + lay.qtypes;
+    // M2W == 1: the candidate mask of query SSE i by ONE LDS read (tmask[qtypes[i]] is two, one after the other,
+    // on the path of every SA step)
+    uint32_t *qmask = reinterpret_cast<uint32_t *>(lds_slot + lay.qmask);
     unsigned char *red_b = lds_slot + lay.red;
     auto red_key = [&](int w) -> unsigned long long * { return reinterpret_cast<unsigned long long *>(red_b + (uint32_t)w * lay.red_stride); };
     constexpr int TMS = M2W;                                  // words per type of the type masks
@@ -714,6 +720,10 @@ sat_sa_kernel(const SatKernelArgs a)
         atomicOr(&tmask[t * TMS + (j >> 5)], 1u << (j & 31));
     }
     __syncthreads();
+    if constexpr (M2W == 1) {
+        for (int i = lane_id; i < N1P; i += nthreads) qmask[i] = tmask[qtypes[i] & 3];
+        __syncthreads();
+    }
 
     uint8_t *smap_b = reinterpret_cast<uint8_t *>(smap);
     uint8_t *bmap_b = reinterpret_cast<uint8_t *>(bmap);
@@ -775,10 +785,14 @@ sat_sa_kernel(const SatKernelArgs a)
                         // u < 0.5 for u = 2^-32 + float(v) * 2^-32 (K.cu:625): float(v) < 2^31, i.e. v below the
                         // first value that rounds up to 2^31 (24-bit mantissa, ties to even)
                         if (!stopped && rv[s] < 0x7FFFFFC0u) {
-                            const int t = qtypes[i];
                             Bits<M2W> cand, below = bits_below<M2W>(j);
+                            if constexpr (M2W == 1) {
+                                cand.w[0] = qmask[i] & ~below.w[0];
+                            } else {
+                                const int t = qtypes[i];
 #pragma unroll
-                            for (int w = 0; w < M2W; w++) cand.w[w] = tmask[t * TMS + w] & ~below.w[w];
+                                for (int w = 0; w < M2W; w++) cand.w[w] = tmask[t * TMS + w] & ~below.w[w];
+                            }
                             int jj = bits_lowest<M2W>(cand);
                             if (jj < 0) {
                                 stopped = true;              // K.cu:633-638: give up, no more draws used
@@ -987,7 +1001,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 // no mapped SSE at or below ssei: startj = n2, empty (K.cu:1060-1063); no mapped
                 // successor: endj = -1, empty, unless ssei is the last query SSE (K.cu:1064-1077)
                 const bool empty = none || (y == 0u && ssei != n1 - 1);
-                cand.w[0] = empty ? 0u : (tmask[qtypes[ssei]] & gap);
+                cand.w[0] = empty ? 0u : (qmask[ssei] & gap);
             } else {
                 oldj = smap_b[map_byte_addr(ssei)];
                 int startj = 0, endj = n2;
