@@ -24,6 +24,11 @@
 //        (same for all lanes): 16-byte and 4-byte loads from consecutive addresses.
 //        Diagonal and padding distances are the sentinel +1e30, which removes the k == i
 //        term (K.cu:524,530).  Read through L1/L2 (32+-SSE queries) or staged in LDS.
+//        Behind the grouped arrays the blob holds the same cells once more as a dense
+//        qpair[i * N1P + k] = {distance, code byte} (8 bytes): the full score of an initial map
+//        walks the matched pairs (i, k) of each chain and fetches one such cell per pair.
+//   qmask (LDS, launches with one-word db sets) per query SSE the db SSEs of its type,
+//        tmask[qtypes[i]]: one read on the path of every SA step instead of two dependent ones.
 //   smap (LDS) per-chain SSE map, one byte per query SSE, stored word-interleaved
 //        smap[w*(T+1) + chain]: word w of every chain is contiguous, so a loop over a
 //        uniform word reads it conflict free; the odd row stride T+1 spreads the words of
