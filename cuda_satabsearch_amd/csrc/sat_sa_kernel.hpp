@@ -953,6 +953,16 @@ sat_sa_kernel(const SatKernelArgs a)
             // pointer gets a vector load, whose latency would sit in front of the table load), asked
             // for here so that they are back long before the test at the end of the step
             const int rowoff = prowC[2 * iter], rowmax = prowC[2 * iter + 1];
+            // The first 64 entries of this step's row, one per lane: a coalesced load asked for here, a whole step
+            // before the test needs it; the test then fetches its entry from the lane that holds it (ds_bpermute)
+            // instead of waiting for a dependent global load at the very end of the step's chain.  Bench shape +3 %
+            // in same-box A/B runs, the other LORDER launches of the 32-SSE classes and up with one-word db sets
+            // 0 .. +0.7 %; not where it measured slower: the 16 class (-5 %), the static loops of LORDER = F
+            // (-1.6 %), 64-SSE entries (-0.8 %).
+            constexpr bool ROW_IN_LANES = N1P >= 32 && M2W == 1 && (OPT < 0 || (OPT & 1) != 0);
+            float rowv = 0.0f;
+            if constexpr (ROW_IN_LANES)
+                rowv = *(gptr_f32)((gptr_c)ptabG + (((uint32_t)rowoff + (uint32_t)min(wlane, rowmax + 2)) << 2));
             // one Philox block per two steps: the even step draws it and uses words 0, 1, the odd step
             // uses words 2, 3 (moved down).  Word a = two 16-bit draws (moved SSE: high half, candidate:
             // low half), word b = the Metropolis draw.
@@ -1219,7 +1229,13 @@ sat_sa_kernel(const SatKernelArgs a)
             // row = { 2^33 (any delta > 0: expf(x > 0) > 1 >= u), P[0], ..., P[rowmax], 0.0 (a larger
             // -delta can never be accepted) }, indexed by 1 - delta clamped to the row
             const uint32_t nd = (uint32_t)min(max(1 - delta, 0), rowmax + 2);
-            const float p = *(gptr_f32)((gptr_c)ptabG + (((uint32_t)rowoff + nd) << 2));
+            float p;
+            // (full waves only: a lane without a restart has not loaded its entry of the row; -delta beyond 62
+            // anywhere in the wave: the load after all)
+            if (ROW_IN_LANES && __builtin_amdgcn_ballot_w64(true) == ~0ull && __builtin_amdgcn_ballot_w64(nd >= 64u) == 0ull)
+                p = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(nd << 2), __float_as_int(rowv)));
+            else
+                p = *(gptr_f32)((gptr_c)ptabG + (((uint32_t)rowoff + nd) << 2));
             const bool accept = p > u;
             if (accept) smap_b[map_byte_addr(ssei)] = (uint8_t)newj;
             score = accept ? newscore : score;
