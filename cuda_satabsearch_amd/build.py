@@ -37,6 +37,17 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def kernel_source_hash():
+    """sha256 over the sources of the SA kernel and its dispatch: profiles/bench_traffic.json carries it, so that
+    bench.py only reports committed counter figures that were measured on the kernel it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sat_sa_kernel.hpp", "sat_capi.hip", "sat_ctx.hpp"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build_host(force=False):
     out = os.path.join(PKG, "libsathost.so")
     srcs = [os.path.join(HOST, f) for f in ("sat_parse.c", "sat_gumbel.c", "sat_shard.c")]

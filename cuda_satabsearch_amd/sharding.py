@@ -58,3 +58,58 @@ def gather_to_rank0(local, total, world, rank, dist=None, group=None, orders=Non
     if rank != 0:
         return None
     return torch.cat([gather_list[r][:bounds[r + 1] - bounds[r]] for r in range(world)])
+
+
+class ShardGather:
+    """The one exchange of a sharded search, set up once and then repeated: every rank's score row goes to
+    rank 0, which holds the whole database's rows in file order.  All buffers are allocated here - a
+    padded send row per slot and, on rank 0, `world` receive rows per slot - and there are two slots,
+    so that the gather of search k (asynchronous: on RCCL it runs on the communicator's own stream)
+    overlaps search k + 1, which writes the context's score buffer again.  The same code runs over
+    gloo on CPU tensors (the tests, and rehearsals on a box with fewer GPUs than ranks)."""
+
+    SLOTS = 2
+
+    def __init__(self, bounds, rank, dist, device, dtype=None, group=None):
+        import torch
+        self.bounds = [int(b) for b in bounds]
+        self.world = len(self.bounds) - 1
+        self.rank = rank
+        self.dist = dist
+        self.group = group
+        self.n_local = self.bounds[rank + 1] - self.bounds[rank]
+        self.width = max(self.bounds[r + 1] - self.bounds[r] for r in range(self.world))
+        dtype = dtype or torch.int32
+        self.send = [torch.zeros(self.width, dtype=dtype, device=device) for _ in range(self.SLOTS)]
+        self.recv = [[torch.empty(self.width, dtype=dtype, device=device) for _ in range(self.world)]
+                     if rank == 0 else None for _ in range(self.SLOTS)]
+        self.work = [None] * self.SLOTS
+        self.k = 0
+
+    def start(self, local):
+        """Queue the gather of `local` (this rank's n_local scores; a device tensor for RCCL, anything
+        copyable into the send row otherwise).  Returns the slot; the row is read when the copy into the
+        slot's send buffer runs, so the caller may overwrite `local` with work queued after this call."""
+        b = self.k % self.SLOTS
+        self.k += 1
+        if self.work[b] is not None:
+            self.work[b].wait()                   # the gather that last used this slot (two searches ago)
+        # (asynchronous only device to device: a non-blocking copy into pageable host memory would not be ordered
+        # with the gather that reads it)
+        self.send[b][:self.n_local].copy_(local[:self.n_local], non_blocking=local.device.type == self.send[b].device.type)
+        self.work[b] = self.dist.gather(self.send[b], self.recv[b], dst=0, group=self.group, async_op=True)
+        return b
+
+    def wait(self, slot=None):
+        for b in (range(self.SLOTS) if slot is None else [slot]):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+
+    def rows(self, slot):
+        """Rank 0: the gathered rows of `slot` in database order (a new tensor of bounds[-1] scores)."""
+        import torch
+        self.wait(slot)
+        if self.rank != 0:
+            return None
+        return torch.cat([self.recv[slot][r][:self.bounds[r + 1] - self.bounds[r]] for r in range(self.world)])

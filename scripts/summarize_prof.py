@@ -16,10 +16,12 @@ if stats:
     shutil.copy(stats[0], os.path.join(dst, name + "_kernel_stats.csv"))
 lines = []
 kern_ns = None
+kern_name = None
 if stats:
     for r in csv.DictReader(open(stats[0])):
         if "sat_sa_" in r["Name"]:
             kern_ns = float(r["AverageNs"])
+            kern_name = r["Name"].split("(")[0].replace("void ", "")
             lines.append(f"kernel {r['Name']}: calls {r['Calls']} avg {kern_ns/1e6:.3f} ms min {float(r['MinNs'])/1e6:.3f} max {float(r['MaxNs'])/1e6:.3f}")
 vals = {}
 for p in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
@@ -57,7 +59,11 @@ if "FETCH_SIZE" in vals:
     lines.append(f"derived: HBM traffic per launch = {fetch/1e6:.1f} MB read (FETCH_SIZE x 1024 x 2) + {wr/1e6:.2f} MB written")
 if "FETCH_SIZE" in vals:
     import json
+    sys.path.insert(0, root)
+    from cuda_satabsearch_amd import build
     json.dump({"source": name + "_summary.txt", "entries_per_launch": entries_per_launch,
+               # which kernel and which sources the figures belong to: bench.py drops them when either differs
+               "kernel": kern_name, "kernel_source_sha256": build.kernel_source_hash(),
                "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals.get("WRITE_SIZE", 0.0),
                "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals.get("WRITE_SIZE", 0.0) * 1024,
                "valu_wave_instr_per_launch": vals.get("SQ_INSTS_VALU"), "lds_wave_instr_per_launch": vals.get("SQ_INSTS_LDS"),

@@ -99,3 +99,58 @@ def test_cuts_degenerate_cases():
     assert sat.sharding.shard_bounds(3, 3, np.array([5, 100, 5])) == [0, 1, 2, 3]      # every shard non-empty
     assert sat.sharding.shard_bounds(8, 2, np.array([111] + [4] * 7)) in ([0, 1, 8], [0, 2, 8])
     assert sat.sharding.shard_bounds(5, 1, np.arange(1, 6)) == [0, 5]
+
+
+def _gather_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import cuda_satabsearch_amd as sat
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bounds = [0, 37, 101]                                   # unequal shards: the shorter row is padded
+    g = sat.sharding.ShardGather(bounds, rank, dist, "cpu")
+    n = bounds[rank + 1] - bounds[rank]
+    local = torch.zeros(n, dtype=torch.int32)
+    got = []
+    for k in range(5):                                      # five "searches": the two slots are reused
+        local[:] = torch.arange(bounds[rank], bounds[rank + 1], dtype=torch.int32) * (k + 1)
+        slot = g.start(local)
+        local[:] = -1                                       # the next search overwrites the score row at once
+        if k >= 3:
+            rows = g.rows(slot)
+            if rank == 0:
+                got.append(rows.numpy().copy())
+    g.wait()
+    if rank == 0:
+        np.save(out_path, np.stack(got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_preallocated_double_buffered_gather(tmp_path):
+    """sharding.ShardGather (bench.py's exchange): buffers allocated once, two slots reused step after step,
+    the send row copied out before the caller's score row is overwritten, rows back in database order."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rows.npy")
+    mp.spawn(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.shape == (2, 101)
+    assert np.array_equal(got[0], np.arange(101) * 4) and np.array_equal(got[1], np.arange(101) * 5)
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` with no torch.distributed environment must start the ranks itself (the parent
+    never touches the GPU).  Here there is no GPU: the ranks say so and the launcher hands their failure on
+    - no hang, no silent success, no result line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the gpu rehearsal test on a GPU box")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "needs a HIP device" in p.stderr
+    assert not any(l.lstrip().startswith("{") for l in p.stdout.splitlines())
