@@ -20,7 +20,7 @@
  * sequential drand48 stream, byte-identical to the reference's -c.  It is never a
  * fallback: without -c a missing GPU is an error.
  *
- * Extensions: -g N (GPUs to use, default all visible), -G 0,2,3 (which GPUs; a GPU named twice
+ * Extensions: -g N (GPUs to use; default 1 as the reference, 0 = all visible), -G 0,2,3 (which GPUs; a GPU named twice
  * holds two shards), -s SEED (Philox seed, default 1234),
  * -k K (print only the K best rows per query, ranked on the GPU by raw score, ties in
  * database order - the `sort -k 2,2nr | head` users run on the reference's output),
@@ -55,7 +55,7 @@ static void usage(const char *prog)
     fprintf(stderr, "  -q dbfile : database is read from dbfile, list of query\n"
                     "              ids is read from stdin\n");
     fprintf(stderr, "  -r restarts : number of restarts. Default %d\n", 128);
-    fprintf(stderr, "  -g gpus : number of GPUs to shard the database over. Default all\n");
+    fprintf(stderr, "  -g gpus : number of GPUs to shard the database over (0 = all visible). Default 1\n");
     fprintf(stderr, "  -G list : the GPUs to use, e.g. 0,2,3 (a GPU named twice holds two shards)\n");
     fprintf(stderr, "  -s seed : seed of the GPU random streams. Default %d\n", SAT_DEFAULT_SEED);
     fprintf(stderr, "  -k K : print only the K best rows per query (GPU mode)\n");
@@ -103,8 +103,10 @@ static void print_header(int ltype, int lorder, int lsoln, const char *qid, cons
 #define N2_SCORE_LO (-256)
 #define N2_SCORE_N 1280                    /* scores -256 .. 1023 */
 #define N2_SUM_N (2 * SAT_MAXDIM + 1)      /* n1 + n2 */
-typedef struct { unsigned char len; char text[23]; } g_text;
-static g_text zp_cache[2][ZP_SLOTS];       /* [wide gap]["z p" of the integer] */
+/* (a text that does not fit its slot is never cached - len stays 0 - and is formatted again row by row) */
+typedef struct { unsigned char len; char text[23]; } g_text;          /* "%g" of a double: at most 13 characters */
+typedef struct { unsigned char len; char text[47]; } zp_text;         /* " %g  %g\n": at most 30 */
+static zp_text zp_cache[2][ZP_SLOTS];      /* [wide gap]["z p" of the integer] */
 static g_text *norm2_cache = NULL;         /* [score - lo][n1 + n2], allocated on first use */
 
 static inline void out_int(int v)
@@ -139,8 +141,11 @@ static void out_row(const char *name, int score, double norm2score, double zscor
     if (si >= 0 && si < N2_SCORE_N && sum >= 0 && sum < N2_SUM_N) {
         if (!norm2_cache) norm2_cache = (g_text *)calloc((size_t)N2_SCORE_N * N2_SUM_N, sizeof(g_text));
         g_text *c = norm2_cache ? &norm2_cache[(size_t)si * N2_SUM_N + sum] : NULL;
-        if (c && !c->len) c->len = (unsigned char)snprintf(c->text, sizeof c->text, "%g", norm2score);
-        if (c) out_bytes(c->text, c->len);
+        if (c && !c->len) {
+            const int n = snprintf(c->text, sizeof c->text, "%g", norm2score);
+            if (n > 0 && (size_t)n < sizeof c->text) c->len = (unsigned char)n;
+        }
+        if (c && c->len) out_bytes(c->text, c->len);
         else { char t[32]; out_bytes(t, (size_t)snprintf(t, sizeof t, "%g", norm2score)); }
     } else {
         char t[32];
@@ -149,9 +154,13 @@ static void out_row(const char *name, int score, double norm2score, double zscor
     /* " z p\n": a function of the truncated norm2 score */
     const int x = (int)norm2score;
     if (stats_from_host && x >= -256 && x < 256) {
-        g_text *c = &zp_cache[wide_gap ? 1 : 0][x + 256];
-        if (!c->len) c->len = (unsigned char)snprintf(c->text, sizeof c->text, wide_gap ? " %g  %g\n" : " %g %g\n", zscore, pvalue);
-        out_bytes(c->text, c->len);
+        zp_text *c = &zp_cache[wide_gap ? 1 : 0][x + 256];
+        if (!c->len) {
+            const int n = snprintf(c->text, sizeof c->text, wide_gap ? " %g  %g\n" : " %g %g\n", zscore, pvalue);
+            if (n > 0 && (size_t)n < sizeof c->text) c->len = (unsigned char)n;
+        }
+        if (c->len) out_bytes(c->text, c->len);
+        else { char t[64]; out_bytes(t, (size_t)snprintf(t, sizeof t, wide_gap ? " %g  %g\n" : " %g %g\n", zscore, pvalue)); }
     } else {
         char t[64];
         out_bytes(t, (size_t)snprintf(t, sizeof t, wide_gap ? " %g  %g\n" : " %g %g\n", zscore, pvalue));
@@ -195,7 +204,7 @@ int main(int argc, char *argv[])
 {
     char dbfile[SAT_MAX_LINE_LEN] = "";
     char buf[SAT_MAX_LINE_LEN];
-    int use_gpu = 1, querydbmode = 0, maxstart = 128, want_gpus = 0, bincache = 0, topk = 0;
+    int use_gpu = 1, querydbmode = 0, maxstart = 128, want_gpus = 1, bincache = 0, topk = 0;
     unsigned long long seed = SAT_DEFAULT_SEED;
     int ltype = 0, lorder = 0, lsoln = 0;
     char cltype = 'F', clorder = 'F', clsoln = 'F';

@@ -124,6 +124,11 @@ int sat_set_append(sat_struct_set *set, const char *name, int order,
     return s;
 }
 
+/* A piece of the threaded reader that was cut at a false record header must not end the process on the
+ * "bad code" it then meets (the sequential parse, which defines the result, may read the same bytes as
+ * distances): a piece parser points this at its own flag, a bad code sets it and the piece is thrown away. */
+static __thread int *t_soft_error = NULL;
+
 static uint8_t ssetype_code(const char *c)
 {
     if (c[0] == 'e')
@@ -133,6 +138,7 @@ static uint8_t ssetype_code(const char *c)
     case 'i': return SAT_SSE_XI;
     case 'g': return SAT_SSE_XG;
     default:
+        if (t_soft_error) { *t_soft_error = 1; return 0; }
         fprintf(stderr, "Bad helix type %c\n", c[1]);
         exit(1);
     }
@@ -142,6 +148,7 @@ static uint8_t nibble_of(char c, const char *alphabet)
 {
     const char *p = c ? strchr(alphabet, c) : NULL;
     if (!p) {
+        if (t_soft_error) { *t_soft_error = 1; return 0; }
         fprintf(stderr, "invalid tableaux code %c\n", c);
         exit(1);
     }
@@ -311,7 +318,11 @@ float sat_distance_cell(const char *text)
     return distance_at(text);
 }
 
-static int read_structures_span(const char *text, size_t len, sat_struct_set *set, const char *what, size_t *consumed)
+/* `incomplete` (may be NULL; given by the piece parsers of the threaded reader): set when the span ended inside a
+ * record - rows still missing at its end - or a cell held no valid code; warnings are then left to the
+ * sequential parse that follows. */
+static int read_structures_span(const char *text, size_t len, sat_struct_set *set, const char *what, size_t *consumed,
+                                int *incomplete)
 {
     char buf[SAT_MAX_LINE_LEN];
     uint8_t *tri_tab = (uint8_t *)malloc(SAT_MAXDIM * (SAT_MAXDIM + 1) / 2);
@@ -327,14 +338,18 @@ static int read_structures_span(const char *text, size_t len, sat_struct_set *se
         free(tri_dist);
         return -1;
     }
-    while (c.p < c.end) {
+    int cut_short = 0;
+    t_soft_error = incomplete ? &cut_short : NULL;
+    while (c.p < c.end && !cut_short) {
         if (scan_header(&c, name, &order) != 2)
             break;
         if (order > SAT_MAXDIM) {
             fprintf(stderr, "Tableau %s order %d is too large (max is %d)\n", name, order, SAT_MAXDIM);
             fprintf(stderr, "WARNING: excluded %s structure %s as it is too large\n", what, name);
-            for (int i = 0; i < 2 * order; i++)
+            for (int i = 0; i < 2 * order; i++) {
+                if (c.p >= c.end) cut_short = 1;
                 next_line(&c, buf, &dirty);
+            }
             skipped++;
             continue;
         }
@@ -345,23 +360,28 @@ static int read_structures_span(const char *text, size_t len, sat_struct_set *se
         }
         int64_t k = 0;
         for (int i = 0; i < order; i++) {
+            if (c.p >= c.end) cut_short = 1;         /* the span ends inside this record (an empty line is read) */
             next_line(&c, buf, &dirty);
             for (int j = 0; j <= i; j++, k++)
                 tri_tab[k] = (i == j) ? ssetype_code(&buf[3 * j]) : tableau_code(&buf[3 * j]);
         }
         k = 0;
         for (int i = 0; i < order; i++) {
+            if (c.p >= c.end) cut_short = 1;
             next_line(&c, buf, &dirty);
             for (int j = 0; j <= i; j++, k++)
                 tri_dist[k] = distance_at(&buf[7 * j]);
         }
         if (sat_set_append(set, name, order, tri_tab, tri_dist) < 0) {
+            t_soft_error = NULL;
             free(tri_tab);
             free(tri_dist);
             return -1;
         }
         added++;
     }
+    t_soft_error = NULL;
+    if (incomplete) *incomplete = cut_short;
     if (skipped > 0)
         fprintf(stderr, "WARNING: skipped %d %s tableaux of order > %d\n", skipped, what, SAT_MAXDIM);
     set->skipped += skipped;
@@ -373,7 +393,7 @@ static int read_structures_span(const char *text, size_t len, sat_struct_set *se
 
 int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, const char *what)
 {
-    return read_structures_span(text, len, set, what, NULL);
+    return read_structures_span(text, len, set, what, NULL, NULL);
 }
 
 /* ---- parallel parse of a memory image: the file is cut at record headers, every piece is parsed by
@@ -381,9 +401,20 @@ int sat_read_structures_mem(const char *text, size_t len, sat_struct_set *set, c
  * begins (a record that claims more rows than it has would run into its neighbour): if any does not,
  * the whole image is parsed again sequentially, which is what defines the result. */
 
-/* does a record header ("name order": two blank-separated tokens, the second all digits) start at p? */
-static int looks_like_header(const char *p, const char *end)
+/* does a record header ("name order": two blank-separated tokens, the second all digits) start at p?  The line
+ * before it must be blank, as the database builder writes it between records (scripts/convdb2.py:226): a row of
+ * integer-formatted distances such as "12 0" has the shape of a header but follows another row.  A file without
+ * blank separators simply finds no cut and is parsed sequentially. */
+static int looks_like_header(const char *text, const char *p, const char *end)
 {
+    if (p > text) {
+        const char *b = p - 1;                       /* the newline that ends the previous line */
+        if (*b != '\n') return 0;
+        while (b > text && b[-1] != '\n') {
+            b--;
+            if (*b != ' ' && *b != '\t' && *b != '\r') return 0;
+        }
+    }
     const char *q = p;
     while (q < end && (*q == ' ' || *q == '\t')) q++;
     int n = 0;
@@ -405,12 +436,13 @@ typedef struct parse_job {
     sat_struct_set set;
     size_t consumed;
     int added;
+    int incomplete;
 } parse_job;
 
 static void *parse_job_run(void *arg)
 {
     parse_job *j = (parse_job *)arg;
-    j->added = read_structures_span(j->text, j->len, &j->set, j->what, &j->consumed);
+    j->added = read_structures_span(j->text, j->len, &j->set, j->what, &j->consumed, &j->incomplete);
     return NULL;
 }
 
@@ -435,7 +467,7 @@ int sat_read_structures_mem_mt(const char *text, size_t len, sat_struct_set *set
         /* the next line start at or after p whose line looks like a record header */
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         p = nl ? nl + 1 : end;
-        while (p < end && !looks_like_header(p, end)) {
+        while (p < end && !looks_like_header(text, p, end)) {
             nl = (const char *)memchr(p, '\n', (size_t)(end - p));
             p = nl ? nl + 1 : end;
         }
@@ -453,7 +485,7 @@ int sat_read_structures_mem_mt(const char *text, size_t len, sat_struct_set *set
     }
     for (int t = 0; t < launched; t++) pthread_join(tid[t], NULL);
     for (int t = 0; ok && t < pieces; t++) {
-        if (jobs[t].added < 0) ok = 0;
+        if (jobs[t].added < 0 || jobs[t].incomplete) ok = 0;
         /* the piece must have been consumed to its end, blanks aside */
         const char *q = jobs[t].text + jobs[t].consumed, *pe = jobs[t].text + jobs[t].len;
         while (q < pe && is_space(*q)) q++;

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -77,6 +78,7 @@ struct sat_multi {
     int pad_rows = 0;                           // largest shard: every shard's rows are padded to it in the gather
     bool use_rccl = false;
     bool force_gather = false;                  // SAT_MULTI_GATHER set: gather also with one GPU (tests)
+    bool rccl_required = false;                 // SAT_MULTI_GATHER=rccl: an RCCL failure is an error, no peer-copy fallback
     std::vector<ncclComm_t> comm;
     // gathered rows on device 0: [ndev][nq * pad_rows] scores, [ndev][pad_rows * sum(n1)] map bytes
     int32_t *d_all_scores = nullptr;
@@ -119,6 +121,30 @@ int grow_stage(sat_multi *m, size_t bytes)
     return SAT_OK;
 }
 
+// the peer-copy path signals "shard g's rows have arrived on device 0" with one event per sender; they are made
+// when that path is first taken (at creation without RCCL, or when a gather falls back to it)
+int ensure_peer_events(sat_multi *m)
+{
+    for (int g = 1; g < m->ndev; g++) {
+        if (m->done[(size_t)g]) continue;
+        HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+        HIP_TRY(hipEventCreateWithFlags(&m->done[(size_t)g], hipEventDisableTiming));
+        (void)hipDeviceEnablePeerAccess(m->devices[0], 0);     // best effort: the copy is staged without it
+        (void)hipGetLastError();
+    }
+    return SAT_OK;
+}
+
+// wait for everything queued on every GPU of the set (before an error return: no search may still be writing
+// result buffers the caller is about to re-use or free); errors of the waits themselves are dropped
+void sync_all(sat_multi *m)
+{
+    for (int g = 0; g < m->ndev; g++) {
+        if (hipSetDevice(m->devices[(size_t)g]) == hipSuccess) (void)hipStreamSynchronize(m->ctx[(size_t)g]->stream);
+        (void)hipGetLastError();
+    }
+}
+
 // bring `count` elements of every device's `src(g)` into block g of `dst` on device 0
 template <typename T, typename Src>
 int gather_to_device0(sat_multi *m, T *dst, size_t count, ncclDataType_t type, Src src)
@@ -126,18 +152,26 @@ int gather_to_device0(sat_multi *m, T *dst, size_t count, ncclDataType_t type, S
     sat_ctx *root = m->ctx[0];
     if (m->use_rccl) {
         ncclResult_t r = g_rccl.GroupStart();
-        if (r != ncclSuccess) return rccl_fail(r, "ncclGroupStart");
-        for (int g = 0; g < m->ndev; g++) {
+        bool ok = r == ncclSuccess;
+        for (int g = 0; ok && g < m->ndev; g++) {
             HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
             r = g_rccl.Gather(src(g), dst, count, type, 0, m->comm[(size_t)g], m->ctx[(size_t)g]->stream);
-            if (r != ncclSuccess) {
-                (void)g_rccl.GroupEnd();
-                return rccl_fail(r, "ncclGather");
-            }
+            ok = r == ncclSuccess;
         }
-        r = g_rccl.GroupEnd();
-        if (r != ncclSuccess) return rccl_fail(r, "ncclGroupEnd");
-        return SAT_OK;
+        if (r != ncclSuccess && ok) ok = false;
+        const ncclResult_t rend = g_rccl.GroupEnd();
+        if (ok && rend == ncclSuccess) return SAT_OK;
+        // RCCL refused the gather at run time: unless the caller insisted on it, take the peer-copy path from
+        // here on (the searches are queued and their rows sit in each GPU's memory; nothing is lost)
+        if (m->rccl_required)
+            return rccl_fail(ok ? rend : r, ok ? "ncclGroupEnd" : "ncclGather");
+        fprintf(stderr, "satabsearch: RCCL gather failed (%s); falling back to peer copies\n",
+                g_rccl.GetErrorString ? g_rccl.GetErrorString(ok ? rend : r) : "RCCL error");
+        sync_all(m);
+        (void)hipGetLastError();
+        m->use_rccl = false;
+        const int rc = ensure_peer_events(m);
+        if (rc != SAT_OK) return rc;
     }
     for (int g = 0; g < m->ndev; g++) {
         sat_ctx *c = m->ctx[(size_t)g];
@@ -200,17 +234,11 @@ sat_multi *sat_multi_create(int ndev, const int *devices, uint64_t seed)
         sat_multi_destroy(m);
         return nullptr;
     }
-    if (!m->use_rccl)
-        for (int g = 1; g < ndev; g++) {
-            if (hipSetDevice(m->devices[(size_t)g]) != hipSuccess ||
-                hipEventCreateWithFlags(&m->done[(size_t)g], hipEventDisableTiming) != hipSuccess) {
-                sat_fail(SAT_EDEVICE, "event creation failed on device %d", m->devices[(size_t)g]);
-                sat_multi_destroy(m);
-                return nullptr;
-            }
-            (void)hipDeviceEnablePeerAccess(m->devices[0], 0);     // best effort: the copy is staged without it
-            (void)hipGetLastError();
-        }
+    m->rccl_required = force_rccl;
+    if (!m->use_rccl && ensure_peer_events(m) != SAT_OK) {
+        sat_multi_destroy(m);
+        return nullptr;
+    }
     return m;
 }
 
@@ -244,6 +272,15 @@ int sat_multi_db_upload_packed(sat_multi *m, int n_entries, const int32_t *order
     if (!m) return sat_fail(SAT_EINVAL, "null context");
     if (n_entries < m->ndev) return sat_fail(SAT_EINVAL, "%d entries cannot be cut into %d shards", n_entries, m->ndev);
     if (!orders || !cell_off || !tab_tri || !dist_tri) return sat_fail(SAT_EINVAL, "null array");
+    // a shard is uploaded as a WINDOW of the packed arrays (from its first entry's first cell): the entries must lie
+    // in file order, one after the other without overlap - what every reader here produces
+    for (int e = 0; e + 1 < n_entries; e++) {
+        const int64_t n = orders[e];
+        if (n < 1 || n > SAT_MAXDIM) return sat_fail(SAT_EINVAL, "entry %d: order %lld outside 1..%d", e, (long long)n, SAT_MAXDIM);
+        if (cell_off[e] < 0 || cell_off[e + 1] < cell_off[e] + n * (n + 1) / 2)
+            return sat_fail(SAT_EINVAL, "entry %d: cell offsets must ascend in file order without overlap for a sharded upload "
+                            "(entry %d starts at cell %lld, entry %d at %lld)", e + 1, e, (long long)cell_off[e], e + 1, (long long)cell_off[e + 1]);
+    }
     m->begin.assign((size_t)m->ndev + 1, 0);
     if (sat_shard_cuts(n_entries, orders, m->ndev, m->begin.data()) != 0) return sat_fail(SAT_EINVAL, "bad database");
     m->n_entries = n_entries;
@@ -306,9 +343,11 @@ int sat_multi_search(sat_multi *m, int lorder, int lsoln, int maxstart, int32_t 
     if (lsoln && !ssemaps) return sat_fail(SAT_EINVAL, "lsoln set but ssemaps buffer is null");
     if (m->begin.empty()) return sat_fail(SAT_ESTATE, "no database uploaded");
     const auto t0 = std::chrono::steady_clock::now();
+    // (an error below waits for the searches already queued on the other GPUs before it is returned)
+    auto bail = [&](int rc) { const std::string msg = sat_last_error(); sync_all(m); return sat_fail(rc, "%s", msg.c_str()); };
     for (int g = 0; g < m->ndev; g++) {
         int rc = sat_search_async(m->ctx[(size_t)g], lorder, lsoln, maxstart);
-        if (rc != SAT_OK) return rc;
+        if (rc != SAT_OK) return bail(rc);
     }
     sat_ctx *root = m->ctx[0];
     const size_t nq = root->queries.size(), N = (size_t)m->n_entries, pad = (size_t)m->pad_rows;
@@ -321,26 +360,30 @@ int sat_multi_search(sat_multi *m, int lorder, int lsoln, int maxstart, int32_t 
     size_t map_bytes_per_row = 0;
     for (const auto &q : root->queries) map_bytes_per_row += (size_t)q.n1;
     const size_t score_count = nq * pad, map_count = pad * map_bytes_per_row;
-    HIP_TRY(hipSetDevice(m->devices[0]));
     int rc;
-    if ((rc = grow_dev(m->d_all_scores, m->all_scores_cap, score_count * (size_t)m->ndev)) != SAT_OK) return rc;
-    if (lsoln && (rc = grow_dev(m->d_all_maps, m->all_maps_cap, map_count * (size_t)m->ndev)) != SAT_OK) return rc;
+    if (hipSetDevice(m->devices[0]) != hipSuccess) return bail(sat_fail(SAT_EDEVICE, "hipSetDevice failed"));
+    if ((rc = grow_dev(m->d_all_scores, m->all_scores_cap, score_count * (size_t)m->ndev)) != SAT_OK) return bail(rc);
+    if (lsoln && (rc = grow_dev(m->d_all_maps, m->all_maps_cap, map_count * (size_t)m->ndev)) != SAT_OK) return bail(rc);
     const size_t stage_bytes = score_count * (size_t)m->ndev * sizeof(int32_t) + (lsoln ? map_count * (size_t)m->ndev : 0);
-    if ((rc = grow_stage(m, stage_bytes)) != SAT_OK) return rc;
+    if ((rc = grow_stage(m, stage_bytes)) != SAT_OK) return bail(rc);
     if ((rc = gather_to_device0(m, m->d_all_scores, score_count, ncclInt32,
-                                [&](int g) { return (const int32_t *)m->ctx[(size_t)g]->d_scores; })) != SAT_OK) return rc;
+                                [&](int g) { return (const int32_t *)m->ctx[(size_t)g]->d_scores; })) != SAT_OK) return bail(rc);
     if (lsoln && (rc = gather_to_device0(m, m->d_all_maps, map_count, ncclInt8,
-                                         [&](int g) { return (const int8_t *)m->ctx[(size_t)g]->d_ssemaps; })) != SAT_OK) return rc;
-    HIP_TRY(hipSetDevice(m->devices[0]));
+                                         [&](int g) { return (const int8_t *)m->ctx[(size_t)g]->d_ssemaps; })) != SAT_OK) return bail(rc);
     int32_t *h_scores = static_cast<int32_t *>(m->h_stage);
     int8_t *h_maps = reinterpret_cast<int8_t *>(h_scores + score_count * (size_t)m->ndev);
-    HIP_TRY(hipMemcpyAsync(h_scores, m->d_all_scores, score_count * (size_t)m->ndev * sizeof(int32_t), hipMemcpyDeviceToHost, root->stream));
-    if (lsoln) HIP_TRY(hipMemcpyAsync(h_maps, m->d_all_maps, map_count * (size_t)m->ndev, hipMemcpyDeviceToHost, root->stream));
-    HIP_TRY(hipStreamSynchronize(root->stream));
-    for (int g = 1; g < m->ndev; g++) {                            // the senders' streams are done too
-        HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
-        HIP_TRY(hipStreamSynchronize(m->ctx[(size_t)g]->stream));
-    }
+    auto to_host = [&]() -> int {
+        HIP_TRY(hipSetDevice(m->devices[0]));
+        HIP_TRY(hipMemcpyAsync(h_scores, m->d_all_scores, score_count * (size_t)m->ndev * sizeof(int32_t), hipMemcpyDeviceToHost, root->stream));
+        if (lsoln) HIP_TRY(hipMemcpyAsync(h_maps, m->d_all_maps, map_count * (size_t)m->ndev, hipMemcpyDeviceToHost, root->stream));
+        HIP_TRY(hipStreamSynchronize(root->stream));
+        for (int g = 1; g < m->ndev; g++) {                            // the senders' streams are done too
+            HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+            HIP_TRY(hipStreamSynchronize(m->ctx[(size_t)g]->stream));
+        }
+        return SAT_OK;
+    };
+    if ((rc = to_host()) != SAT_OK) return bail(rc);
     m->d2h_bytes += stage_bytes;
     // rows of shard g: scores [nq][n_g] at block g; maps: query q's [n_g][n1_q] block after those of queries 0..q-1
     for (int g = 0; g < m->ndev; g++) {
@@ -371,9 +414,10 @@ int sat_multi_search_topk(sat_multi *m, int lorder, int lsoln, int maxstart, int
     if (!hits || k < 1) return sat_fail(SAT_EINVAL, "bad top-k arguments");
     if (m->begin.empty()) return sat_fail(SAT_ESTATE, "no database uploaded");
     const auto t0 = std::chrono::steady_clock::now();
+    auto bail = [&](int rc) { const std::string msg = sat_last_error(); sync_all(m); return sat_fail(rc, "%s", msg.c_str()); };
     for (int g = 0; g < m->ndev; g++) {
         int rc = sat_search_async(m->ctx[(size_t)g], lorder, lsoln, maxstart);
-        if (rc != SAT_OK) return rc;
+        if (rc != SAT_OK) return bail(rc);
     }
     if (k > m->n_entries) k = m->n_entries;
     const int nq = (int)m->ctx[0]->queries.size();
@@ -385,7 +429,7 @@ int sat_multi_search_topk(sat_multi *m, int lorder, int lsoln, int maxstart, int
         cand[(size_t)g].resize((size_t)nq * k);
         if (ssemaps) cmaps[(size_t)g].resize((size_t)nq * k * SAT_MAXDIM);
         const int r = sat_topk_hits(m->ctx[(size_t)g], k, cand[(size_t)g].data(), ssemaps ? cmaps[(size_t)g].data() : nullptr);
-        if (r < 0) return r;
+        if (r < 0) return bail(r);
         got[(size_t)g] = r;
     }
     for (int q = 0; q < nq; q++) {

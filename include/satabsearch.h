@@ -268,13 +268,18 @@ void sat_debug_lds_layout(int m2w, int n1, int n1p, int n2, int chains, int thre
  * holds one context per GPU; the database is cut into contiguous shards of equal COST
  * (csrc/host/sat_shard.h: real databases are size sorted and a 96-SSE entry costs four 32-SSE
  * ones), each GPU holds its shard and the queries, a search is queued on all of them and ONE
- * gather (RCCL ncclGather over xGMI; SAT_MULTI_GATHER=peer: hipMemcpyPeerAsync) brings the shard
+ * gather (RCCL ncclGather over xGMI; SAT_MULTI_GATHER=peer: hipMemcpyPeerAsync; an RCCL gather that fails
+ * at run time falls back to the peer copies for the rest of the context's life unless
+ * SAT_MULTI_GATHER=rccl insists) brings the shard
  * rows to device 0, from where one copy takes them to the host in database file order.  Results
  * are identical for any number of GPUs (streams are keyed by the entry's ordinal in the database).
  *
  * sat_multi_create      ndev GPUs (<= 0: all visible; devices == NULL: 0 .. ndev-1; a list may name a GPU more
  *                       than once - several shards on one GPU, gathered by peer copies)
- * sat_multi_db_upload_packed   as sat_db_upload_packed for the WHOLE database (ordinals = file order)
+ * sat_multi_db_upload_packed   as sat_db_upload_packed for the WHOLE database (ordinals = file order), with ONE more
+ *                       requirement: cell_off must ascend in file order without overlap (entry e + 1 starts at or
+ *                       after the end of entry e - what every reader here produces), because a shard is uploaded
+ *                       as a window of the packed arrays; anything else is SAT_EINVAL
  * sat_multi_shards      begin[ndev + 1]: shard g holds entries begin[g] .. begin[g+1]-1
  * sat_multi_queries_set as sat_queries_set, on every GPU
  * sat_multi_search      as sat_search: scores [nq][n_entries] (and ssemaps) in database order;

@@ -84,7 +84,7 @@ typedef struct chain_draws {
 static void chain_begin(chain_draws *c, sa_oracle_rng *rng, uint32_t db_ordinal, uint32_t restart)
 {
     c->rng = rng;
-    if (rng->mode == SA_RNG_PHILOX) {
+    if (rng->mode != SA_RNG_DRAND48) {
         uint64_t seed_q = rng->seed + ((uint64_t)rng->query_ordinal << 32);
         c->key[0] = (uint32_t)seed_q;
         c->key[1] = (uint32_t)(seed_q >> 32);
@@ -125,6 +125,8 @@ static float chain_draw16(chain_draws *c, int block, int word, int half)
     if (c->rng->mode == SA_RNG_DRAND48)
         return (float)lcg_drand48(&c->rng->lcg);
     uint32_t w = chain_word(c, block, word);
+    if (c->rng->mode == SA_RNG_PHILOX32)          /* comparison mode: a whole word per index draw (sa_oracle.h) */
+        return sa_oracle_u32_to_uniform(w);
     return sa_oracle_u16_to_uniform(half ? (w >> 16) : (w & 0xFFFFu));
 }
 
@@ -286,7 +288,10 @@ void sa_oracle_search(const sa_oracle_query *q, int dbsize, const int *orders,
             float temp = k_temp0;
             for (int iter = 0; iter < SA_MAXITER; iter++) {
                 /* PHILOX: one block per two steps, two words per step (sa_oracle.h) */
-                const int block = SA_PHILOX_STEP_BLOCK0 + (iter >> 1), word_a = 2 * (iter & 1), word_b = word_a + 1;
+                /* PHILOX32 (comparison mode): one block per step, a whole word per draw */
+                const int wide = rng->mode == SA_RNG_PHILOX32;
+                const int block = SA_PHILOX_STEP_BLOCK0 + (wide ? iter : (iter >> 1));
+                const int word_a = wide ? 0 : 2 * (iter & 1), word_c = wide ? 1 : word_a, word_b = wide ? 2 : word_a + 1;
                 float u = chain_draw16(&draws, block, word_a, 1);
                 int ssei = (int)((u - SA_EPS) * n1);
 
@@ -296,7 +301,7 @@ void sa_oracle_search(const sa_oracle_query *q, int dbsize, const int *orders,
                     endj = upper_bound_image(ssemap, ssei, n1, n2);
                 }
                 int newj = pick_free_same_type(types2, revmap, startj, endj,
-                                               q->ssetypes[ssei], &draws, block, word_a);
+                                               q->ssetypes[ssei], &draws, block, word_c);
                 if (sa_oracle_trace) {
                     /* same line format as the reference DEBUG build (kernel.cu:1092-1096) */
                     printf("%d %d %d %d %d %d %d\n", 0, restart, iter, ssei, startj, endj, newj);

@@ -43,6 +43,12 @@ extern "C" {
 
 #define SA_RNG_DRAND48 0
 #define SA_RNG_PHILOX  1
+/* Comparison mode, not a parity target: as SA_RNG_PHILOX but the two index draws of an SA step take a whole
+ * 32-bit word each at curand_uniform's resolution (one block per step: word 0 = which query SSE, word 1 = which
+ * candidate, word 2 = Metropolis).  The kernel's 16-bit index draws give bins of 590 or 591 values per index for
+ * n = 111 (at most 0.17 % apart) where 32-bit draws are uniform to 2^-25; tests/test_oracle_golden.py checks that
+ * the two modes differ by no more than two seeds of the reference's own stream do. */
+#define SA_RNG_PHILOX32 2
 
 /* Philox draw-slot layout shared with the GPU kernel (DESIGN.md "random stream"):
  *   block b of chain (query, db entry, restart) = Philox4x32-10 with

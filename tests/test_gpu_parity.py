@@ -663,43 +663,26 @@ def test_overlapped_upload_rejects_what_the_plain_upload_rejects(monkeypatch):
 
 
 # ---------------------------------------------------------------- reference -c stream (T3)
-def test_statistically_consistent_with_reference_host_output(searcher, small_db, golden_dir):
+@pytest.mark.parametrize("job", ["c1_d1ubia_small.r128", "d2phlb1.r4096", "d1twfa_.r128", "d2phlb1_TFT.r128", "multiquery.r128"])
+def test_statistically_consistent_with_reference_host_output(searcher, small_db, golden_dir, job):
     """The reference's `-c` run draws from ONE sequential drand48 stream, which no parallel run can
     replay (its own GPU path does not either).  Against its golden stdout the GPU result must look
     like one more seed of the SAME algorithm: tests/golden/expected/seed_spread.json holds the
-    entry-by-entry comparison of every pair of 8 drand48 seeds of the `-c` semantics on these two
-    jobs (tests/golden/make_seed_spread.py), and the GPU-vs-golden figures must lie inside the
-    measured ranges: fraction of entries that differ within [min - 0.03, max + 0.03], largest
-    |difference| at most the largest seen + 2, |mean difference| at most the largest seen + 0.05,
-    rank correlation at least the smallest seen - 0.01."""
-    import json
-    spread = json.load(open(os.path.join(ROOT, "tests/golden/expected/seed_spread.json")))["jobs"]
-
-    def inside(job, gpu, ref):
-        band = spread[job]["band"]
-        diff = gpu - ref
-        frac, mx, mean = float((diff != 0).mean()), int(np.abs(diff).max()), float(diff.mean())
-        rc = float(np.corrcoef(np.argsort(np.argsort(gpu)), np.argsort(np.argsort(ref)))[0, 1])
-        print(f"\n{job}: GPU vs golden: {frac:.3f} of entries differ (band {band['frac_differing']}), max |diff| {mx} "
-              f"(band {band['max_abs']}), mean {mean:+.3f} (|band| {band['abs_mean']}), rank corr {rc:.4f} (band {band['rank_corr']})")
-        assert band["frac_differing"][0] - 0.03 <= frac <= band["frac_differing"][1] + 0.03
-        assert mx <= band["max_abs"][1] + 2
-        assert abs(mean) <= band["abs_mean"][1] + 0.05
-        assert rc >= band["rank_corr"][0] - 0.01
-
-    # 8-SSE query, r = 128, against the reference sources' stdout (BASELINE configs[0] / [1])
-    exp = open(os.path.join(ROOT, "tests/golden/expected/c1_d1ubia_small.r128.out")).read().splitlines()[3:]
-    ref = np.array([int(l.split()[1]) for l in exp])
+    entry-by-entry comparison of every pair of 8 drand48 seeds of the `-c` semantics on five jobs
+    (tests/golden/make_seed_spread.py) - the 8-SSE query of BASELINE configs[0] / [1], the 19-SSE query at
+    r = 4096 against the stdout the reference recorded in 2013, the 101-SSE query (large-query path), LORDER = F
+    with solution maps, and a three-query stream - and the GPU-vs-golden figures must lie inside the measured
+    ranges (tests/t3_band.py): fraction of entries that differ within [min - 0.03, max + 0.03], largest
+    |difference| at most the largest seen + 2, |mean difference| at most the largest seen + 0.05, rank
+    correlation at least the smallest seen - 0.01, and with LSOLN the fraction of identical solution maps."""
+    import t3_band
+    stdin_file, _, restarts, lorder, lsoln = t3_band.JOBS[job]
+    qs = sat.StructSet.read(os.path.join(golden_dir, stdin_file), "query", skip_header_lines=2)
     searcher.upload(small_db)
-    searcher.set_query(*load_query(golden_dir, "c1_d1ubia_small.input"), 0)
-    gpu, _, _ = searcher.search(True, False, 128)
-    inside("c1_d1ubia_small.r128", gpu, ref)
-    # 19-SSE query at r = 4096 against the stdout the reference recorded in 2013
-    exp4k = open(os.path.join(ROOT, "tests/golden/expected/recorded_2013_d2phlb1.r4096.out")).read().splitlines()
-    ref4k = {l.split()[0]: int(l.split()[1]) for l in exp4k if not l.startswith("#")}
-    searcher.set_query(*load_query(golden_dir, "d2phlb1.input"), 0)
-    gpu4k, _, _ = searcher.search(True, False, 4096)
-    inside("d2phlb1.r4096", gpu4k, np.array([ref4k[n] for n in small_db.names]))
+    searcher.set_queries([(*qs.dense(k), qs.ssetypes(k)) for k in range(len(qs))], 0)
+    scores, maps, _ = searcher.search(lorder, lsoln, restarts)
+    run_maps = [[t3_band.map_pairs(maps[q, e]) for e in range(len(small_db))] for q in range(len(qs))] if lsoln else None
+    t3_band.check(job, small_db.names, scores, run_maps)
 
 
 # ---------------------------------------------------------------- full benchmark size

@@ -231,6 +231,29 @@ def test_parallel_reader_equals_sequential(tmp_path, monkeypatch):
     assert par.names == seq.names and np.array_equal(par.tab, seq.tab) and np.array_equal(par.dist, seq.dist)
 
 
+@pytest.mark.parametrize("blank_first_row", [False, True])
+def test_parallel_reader_is_not_fooled_by_rows_shaped_like_headers(tmp_path, monkeypatch, blank_first_row):
+    """Hand-written databases may hold integer-formatted distance rows: "12 0" has the shape of a record header
+    ("name order").  The threaded reader must not cut there: a candidate needs a blank line before it, and if
+    even that is met (a record whose first distance row is an empty line) the piece before the false cut ends
+    inside a record, is reported incomplete, and the sequential parse - which defines the result - takes over;
+    a piece that starts at a false header must never end the process on the "bad code" it then meets."""
+    rec = "e  \nPE e  \n" + ("\n" if blank_first_row else "0\n") + "12 0\n\n"
+    text = "".join("s%07d    2\n%s" % (k, rec) for k in range(110_000))
+    path = tmp_path / "int_rows.ascii"
+    open(path, "w").write(text)
+    assert os.path.getsize(path) > 3 << 20
+    monkeypatch.setenv("SAT_PARSE_THREADS", "1")
+    seq = sat.StructSet.read(path)
+    assert len(seq) == 110_000 and set(seq.orders.tolist()) == {2}
+    assert np.array_equal(seq.dist[:3], np.array([0.0, 12.0, 0.0], np.float32))
+    for threads in ("2", "3", "5"):
+        monkeypatch.setenv("SAT_PARSE_THREADS", threads)
+        par = sat.StructSet.read(path)
+        assert par.names == seq.names and np.array_equal(par.orders, seq.orders)
+        assert np.array_equal(par.tab, seq.tab) and np.array_equal(par.dist, seq.dist)
+
+
 def test_ascii_writer_round_trip(tmp_path):
     """sat_set_write_ascii writes the database builder's format (scripts/convdb2.py:214-226): the same
     bytes as the independent Python writer, and the reader gives the structures back exactly - all four

@@ -111,3 +111,56 @@ def test_readme_printed_rows_are_a_stale_vector(golden_dir):
     for seed in ("1", "2", "3"):
         rows = run_cli(golden_dir, "readme_1ubq.input", "-r", "128", "-S", seed).decode().splitlines()[3:7]
         assert [int(l.split()[1]) for l in rows] == [11, 5, 2, 3]
+
+
+# ---------------------------------------------------------------- T3 on the CPU: the kernel's streams against `-c`
+@pytest.fixture(scope="module")
+def small_db_cpu(golden_dir):
+    import cuda_satabsearch_amd as sat
+    return sat.StructSet.read(os.path.join(golden_dir, "tableauxdistmatrixdb.small.ascii"))
+
+
+@pytest.mark.parametrize("job", ["c1_d1ubia_small.r128", "d1twfa_.r128", "d2phlb1_TFT.r128", "multiquery.r128"])
+def test_philox_streams_look_like_one_more_seed_of_the_reference(golden_dir, small_db_cpu, job):
+    """The statement of the GPU's T3 test without a GPU: the oracle on the KERNEL's random streams (Philox, 16-bit
+    index draws - bit-identical to the kernel, tests/test_gpu_parity.py) against the reference's golden `-c` stdout
+    lies inside the measured seed-to-seed spread of the reference's own stream (tests/t3_band.py), for the 8-SSE
+    query, the 101-SSE query, LORDER = F with solution maps and the three-query stream.  (The r = 4096 job is left to
+    the GPU test: 30 s of oracle time.)"""
+    import cuda_satabsearch_amd as sat
+    import oracle_lib
+    import t3_band
+    stdin_file, _, restarts, lorder, lsoln = t3_band.JOBS[job]
+    qs = sat.StructSet.read(os.path.join(golden_dir, stdin_file), "query", skip_header_lines=2)
+    scores, maps = [], []
+    for k in range(len(qs)):
+        t, d = qs.dense(k)
+        sc, mp, _ = oracle_lib.search(small_db_cpu, t, d, qs.ssetypes(k), lorder, lsoln, restarts, query_ordinal=k)
+        scores.append(sc)
+        if lsoln:
+            maps.append([t3_band.map_pairs(mp[e]) for e in range(len(small_db_cpu))])
+    t3_band.check(job, small_db_cpu.names, scores, maps if lsoln else None)
+
+
+def test_sixteen_bit_index_draws_against_full_resolution_draws(golden_dir, small_db_cpu):
+    """The kernel picks the moved SSE and the candidate with 16-bit draws, (v16 + 1) * 2^-16: for
+    n up to 111 the bins hold 590 or 591 of the 65536 values - at most 0.17 % apart - where the reference draws
+    float uniforms at full resolution (curand_uniform / drand48).  A distribution change, however small: the oracle's
+    comparison mode SA_RNG_PHILOX32 (a whole word per index draw) against the shipped layout must differ by no more
+    than two seeds of the reference's own stream do, on the 8-SSE and the 101-SSE query."""
+    import json
+    import numpy as np
+    import cuda_satabsearch_amd as sat
+    import oracle_lib
+    spread = json.load(open(os.path.join(ROOT, "tests/golden/expected/seed_spread.json")))["jobs"]
+    for job, inp in (("c1_d1ubia_small.r128", "c1_d1ubia_small.input"), ("d1twfa_.r128", "d1twfa_.input")):
+        qs = sat.StructSet.read(os.path.join(golden_dir, inp), "query", skip_header_lines=2)
+        t, d = qs.dense(0)
+        a, _, _ = oracle_lib.search(small_db_cpu, t, d, qs.ssetypes(0), True, False, 128)
+        b, _, _ = oracle_lib.search(small_db_cpu, t, d, qs.ssetypes(0), True, False, 128, mode=2)
+        band = spread[job]["band"]
+        diff = b - a
+        frac, mx, mean = float((diff != 0).mean()), int(np.abs(diff).max()), float(diff.mean())
+        print(f"\n{job}: 16-bit vs 32-bit index draws: {frac:.3f} differ, max {mx}, mean {mean:+.3f}; seed-to-seed band {band}")
+        assert frac <= band["frac_differing"][1] + 0.03 and mx <= band["max_abs"][1] + 2
+        assert abs(mean) <= band["abs_mean"][1] + 0.05
