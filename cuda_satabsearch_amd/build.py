@@ -102,6 +102,17 @@ def build_test_native(force=False):
     out = os.path.join(tdir, "librocrand_check.so")
     if force or _stale(out, [src, os.path.join(CSRC, "sat_sa_kernel.hpp")]):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INC, "-I", CSRC, "-o", out, src])
+    # the device library once more with the reference's TESTING assertion compiled in (diag/sat_diag.hpp,
+    # -DSAT_DIAG_SELFCHECK: every proposed move's score against a full recomputation) - loaded only by
+    # tests/test_gpu_parity.py::test_every_move_passes_the_references_self_check, through SAT_DEVICE_LIB
+    out3 = os.path.join(tdir, "libsat_selfcheck.so")
+    dsrcs = [os.path.join(CSRC, f) for f in ("sat_capi.hip", "sat_topk.hip", "sat_multi.hip")]
+    ddeps = dsrcs + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
+                     os.path.join(CSRC, "diag", "sat_diag.hpp"), os.path.join(INC, "satabsearch.h")]
+    if force or _stale(out3, ddeps):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-DSAT_DIAG",
+              "-DSAT_DIAG_SELFCHECK", "-I", INC, "-I", CSRC, "-o", out3] + dsrcs +
+             ["-Wl," + os.path.join(PKG, "sat_gumbel.o"), "-Wl," + os.path.join(PKG, "sat_shard.o"), "-lm", "-ldl"])
     src2, out2 = os.path.join(tdir, "lds_residency.hip"), os.path.join(tdir, "liblds_residency.so")
     if os.path.exists(src2) and (force or _stale(out2, [src2])):
         _run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out2, src2])

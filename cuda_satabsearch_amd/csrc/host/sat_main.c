@@ -379,6 +379,16 @@ int main(int argc, char *argv[])
                               ssemaps ? ssemaps + (size_t)d * SAT_MAXDIM : NULL, lsoln, 0);
             }
         }
+        /* main owns every host array (as H.cu:1314-1324) */
+        free(scores);
+        free(ssemaps);
+        free(qindex);
+        free(sid_list);
+        free(cls_index[0]);
+        free(cls_index[1]);
+        free(norm2_cache);
+        sat_set_free(&queries);
+        sat_set_free(&db);
         return 0;
     }
 
@@ -538,5 +548,22 @@ bye:
     fprintf(stderr, "copied %llu bytes of results from the GPU(s)\n", sat_multi_stat_d2h_bytes(multi));
     sat_multi_destroy(multi);
     (void)cltype; (void)clorder; (void)clsoln;
+    free(scores);
+    free(ssemaps);
+    free(hits);
+    free(hit_maps);
+    free(large_scores);
+    free(large_maps);
+    free(qtabs);
+    free(qdmats);
+    free(qtypes);
+    free(n1s);
+    free(qindex);
+    free(sid_list);
+    free(cls_index[0]);
+    free(cls_index[1]);
+    free(norm2_cache);
+    sat_set_free(&queries);
+    sat_set_free(&db);
     return exit_status;
 }

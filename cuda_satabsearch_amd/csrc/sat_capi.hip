@@ -20,6 +20,9 @@
 #include <vector>
 
 #include "satabsearch.h"
+#ifdef SAT_DIAG
+#define SAT_DIAG_HOST 1           // diagnostic builds only: the counters' host side (diag/sat_diag.hpp)
+#endif
 #include "sat_sa_kernel.hpp"
 #include "sat_ctx.hpp"
 #include "host/sat_gumbel.h"
@@ -352,11 +355,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     a.prow = ctx->d_prow;
     a.bmap_slabs = nullptr;
     a.bmap_slab_words = 0;
-#ifdef SAT_PHASE_TIMING
-    static unsigned long long *d_phase = nullptr;
-    if (!d_phase) HIP_TRY(hipMalloc(&d_phase, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d_phase, 0, 8 * sizeof(unsigned long long), stream));
-    a.phase = d_phase;
+#ifdef SAT_DIAG
+    HIP_TRY(satdiag::begin(stream, a.diag));
 #endif
 
     struct Planned {
@@ -553,18 +553,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                  (plan[i].count + plan[i].epw - 1) / plan[i].epw, plan[i].nqc, plan[i].epw, plan[i].threads, plan[i].lds);
         ctx->last_launch_info += buf;
     }
-#ifdef SAT_PHASE_TIMING
-    {
-        unsigned long long h[8];
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemcpy(h, d_phase, sizeof h, hipMemcpyDeviceToHost));
-        unsigned long long tot = 0;
-        for (int k = 0; k < 8; k++) tot += h[k];
-        static const char *nm[8] = { "draw+proposal", "compaction set-up", "compacted rounds", "read-back/static loops",
-                                     "best tracking", "metropolis+update", "thinit+full score", "restart loop" };
-        for (int k = 0; k < 8; k++)
-            fprintf(stderr, "phase %-24s %14llu wave-cycles %5.1f%%\n", nm[k], h[k], tot ? 100.0 * h[k] / tot : 0.0);
-    }
+#ifdef SAT_DIAG
+    HIP_TRY(satdiag::end(stream));
 #endif
     return SAT_OK;
 }

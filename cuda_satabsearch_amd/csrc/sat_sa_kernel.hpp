@@ -95,10 +95,46 @@
 #include <type_traits>
 #include <stdint.h>
 
-#define SAT_K_MAXITER 100
-#ifndef SAT_FS_UNROLL
-#define SAT_FS_UNROLL 2               // pairs per lane and round of the full score of an initial map
+// Hook points of the diagnostic builds (phase timers, perturbations, duplicated LDS accesses, the per-move
+// self-check): their code lives in diag/sat_diag.hpp, which the shipped library does not include - every hook is
+// nothing here.
+#ifdef SAT_DIAG
+#include "diag/sat_diag.hpp"
 #endif
+#ifndef SAT_DIAG_ARGS
+#define SAT_DIAG_ARGS
+#endif
+#ifndef SAT_PHASE_INIT
+#define SAT_PHASE_INIT
+#define SAT_PHASE(k)
+#define SAT_PHASE_FLUSH
+#endif
+#ifndef SAT_DIAG_FS_ROWS_ONLY
+#define SAT_DIAG_FS_ROWS_ONLY 0
+#endif
+#ifndef SAT_DIAG_DUP_CELLS
+#define SAT_DIAG_DUP_CELLS(row, l0, l1, l2, l3)
+#endif
+#ifndef SAT_DIAG_DUP_MAPWORD
+#define SAT_DIAG_DUP_MAPWORD(p)
+#endif
+#ifndef SAT_DIAG_DUP_ATOMIC
+#define SAT_DIAG_DUP_ATOMIC(p)
+#endif
+#ifndef SAT_DIAG_DUP_MAPBYTE
+#define SAT_DIAG_DUP_MAPBYTE(p)
+#endif
+#ifndef SAT_DIAG_PERTURB_INIT
+#define SAT_DIAG_PERTURB_INIT
+#define SAT_DIAG_PERTURB_STEP
+#define SAT_DIAG_PERTURB_END
+#endif
+#ifndef SAT_DIAG_SELFCHECK_STEP
+#define SAT_DIAG_SELFCHECK_STEP
+#endif
+
+#define SAT_K_MAXITER 100
+#define SAT_FS_UNROLL 2               // pairs per lane and round of the full score of an initial map
 #define SAT_K_STEP_BLOCK0 32          // Philox block of SA step 0 (oracle/sa_oracle.h)
 #define SAT_K_EPS 1.1e-7              // K.cu:67
 #define SAT_K_NO_SCORE (-99999)       // K.cu:1009
@@ -144,9 +180,7 @@ struct SatKernelArgs {
     // Metropolis table
     const float    *ptab;         // ragged rows { 2^33, 2^32 * expf(-nd / temp) for nd = 0 .. last, 0.0 }
     const int32_t  *prow;         // [100][2] = {row offset, largest tabulated -delta}
-#ifdef SAT_PHASE_TIMING
-    unsigned long long *phase;    // [8] wave-cycles per SA-step phase (diagnostic builds only, scripts/exp/variant_lib.sh)
-#endif
+    SAT_DIAG_ARGS                 // diagnostic builds only (diag/sat_diag.hpp): their counters
 };
 
 namespace satk {
@@ -292,16 +326,7 @@ __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, co
 {
     const uint32_t l0 = word & 0xFFu, l1 = (word >> 8) & 0xFFu, l2 = (word >> 16) & 0xFFu, l3 = word >> 24;
     uint2 d0, d1, d2, d3;
-#if defined(SAT_DUP) && SAT_DUP == 1
-    // diagnostic build (scripts/exp/ablate_lds.sh): every db-cell gather is issued a second time (volatile,
-    // result dropped): scores unchanged, the LDS counters grow by exactly this access site's share
-    if constexpr (!SPLIT) {
-        typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_vu64;
-        const unsigned long long dup0 = *(lds_vu64)&row.cells[l0], dup1 = *(lds_vu64)&row.cells[l1],
-                                 dup2 = *(lds_vu64)&row.cells[l2], dup3 = *(lds_vu64)&row.cells[l3];
-        asm volatile("" : : "v"(dup0), "v"(dup1), "v"(dup2), "v"(dup3));
-    }
-#endif
+    SAT_DIAG_DUP_CELLS(row, l0, l1, l2, l3);
     if constexpr (SPLIT) {
         d0 = uint2{ __float_as_uint(row.dist[l0]), row.code[l0] };
         d1 = uint2{ __float_as_uint(row.dist[l1]), row.code[l1] };
@@ -490,48 +515,8 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
     return lds_layout(n2 <= 32 ? 1 : (n2 <= 64 ? 2 : 4), n2, map_words((n1 + 3) >> 2), n1p, chains, threads, q_in_lds, compact).total;
 }
 
-#ifdef SAT_EXP_PERTURB
-// Diagnostic builds only (scripts/exp/variant_lib.sh): extra instructions of one kind per SA step, to see
-// which issue resource the step loop is sensitive to.  1: 40 full-rate VALU, 2: 40 SALU, 3: 10 LDS
-// reads + wait, 4: 40 s_nop, 5: 40 half-rate VALU.
-#define SAT_R10(x) x x x x x x x x x x
-__device__ __forceinline__ void perturb(uint32_t (&d)[4])
-{
-#if SAT_EXP_PERTURB == 1
-    asm volatile(SAT_R10("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n")
-                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-#elif SAT_EXP_PERTURB == 2
-    uint32_t s0 = __builtin_amdgcn_readfirstlane(d[1]), s1 = __builtin_amdgcn_readfirstlane(d[2]);
-    asm volatile(SAT_R10("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %0, %0, 3\n s_add_u32 %1, %1, 3\n")
-                 : "+s"(s0), "+s"(s1) : : "scc");
-    d[1] = s0; d[2] = s1;
-#elif SAT_EXP_PERTURB == 3
-    uint32_t addr = (threadIdx.x & 63u) << 2, t0, t1;
-    asm volatile("ds_read_b32 %0, %2\n ds_read_b32 %1, %2 offset:256\n ds_read_b32 %0, %2 offset:512\n ds_read_b32 %1, %2 offset:768\n"
-                 "ds_read_b32 %0, %2 offset:1024\n ds_read_b32 %1, %2 offset:1280\n ds_read_b32 %0, %2 offset:1536\n"
-                 "ds_read_b32 %1, %2 offset:1792\n ds_read_b32 %0, %2 offset:2048\n ds_read_b32 %1, %2 offset:2304\n s_waitcnt lgkmcnt(0)\n"
-                 : "=&v"(t0), "=&v"(t1) : "v"(addr) : "memory");
-    d[0] ^= t0 & t1 & 0x80000000u;
-#elif SAT_EXP_PERTURB == 4
-    asm volatile(SAT_R10("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"));
-#elif SAT_EXP_PERTURB == 5
-    asm volatile(SAT_R10("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n")
-                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-#endif
-}
-#endif
-
 }  // namespace satk
 
-#ifdef SAT_PHASE_TIMING
-#define SAT_PHASE_INIT unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t0 = __builtin_amdgcn_s_memtime()
-#define SAT_PHASE(k) do { const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime(); ph_acc[k] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
-#define SAT_PHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(a.phase + k, ph_acc[k]); } while (0)
-#else
-#define SAT_PHASE_INIT
-#define SAT_PHASE(k)
-#define SAT_PHASE_FLUSH
-#endif
 
 // N1P: pitch of the query cell matrix (>= 4*ceil(n1/4)); M2W: 32-bit words of a db-side
 // bit set (n2 <= 32*M2W); QLDS: query cells staged in LDS (else read through L1/L2).
@@ -737,6 +722,40 @@ sat_sa_kernel(const SatKernelArgs a)
     const int T4 = TP << 2, tid4 = tid << 2;
     auto map_byte_addr = [&](int k) -> int { return __mul24(k >> 2, T4) + tid4 + (k & 3); };
 
+    // Full score of this lane's chain in the rows-in-step form (tmscord, K.cu:396-440): every lane walks all n1 rows of
+    // its chain, the wave reads the query cells with scalar loads; lanes that share a chain split the words and
+    // the caller adds their sums.
+    auto score_rows = [&]() -> int {
+        int total = 0;
+        for (int i = 0; i < n1 - 1; i++) {
+            // an unmatched SSE has no row in LDS: its lane walks row 0 and drops the sum
+            const int j = smap_b[map_byte_addr(i)];
+            const bool jreal = j != NULLJ;
+            const DbRow<SPLIT> drow = db_row(jreal ? j : 0);
+            int rowsum = 0;
+            auto row_group = [&](int kw) {
+                // pairs with k <= i inside the first word are switched off (mask from i and kw)
+                const int below = i + 1 - 4 * kw;
+                const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
+                const uint32_t qi = (uint32_t)(kw * N1P + i);
+                rowsum = quad_terms(load_qdist(qi << 4), load_qcode(qi << 2), drow, smap[kw * TP + tid], force, rowsum);
+            };
+            // one lane per chain: the group index stays in scalar registers, and so do the query cells
+            if (lpc == 1) {
+                for (int kw = (i + 1) >> 2; kw < n1w; kw++) {
+                    const int below = i + 1 - 4 * kw;
+                    const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
+                    const uint32_t qi = (uint32_t)(kw * N1P + i);
+                    rowsum = quad_terms(load_qdist_uniform(qi), load_qcode_uniform(qi), drow, smap[kw * TP + tid], force, rowsum);
+                }
+            } else {
+                for (int kw = ((i + 1) >> 2) + part; kw < n1w; kw += lpc) row_group(kw);
+            }
+            total += jreal ? rowsum : 0;
+        }
+        return total;
+    };
+
     const uint64_t subseq_lo = (uint64_t)a.ordinal[e];
     int best = SAT_K_NO_SCORE;
     uint32_t best_restart = 0xFFFFFFFFu;
@@ -759,9 +778,7 @@ sat_sa_kernel(const SatKernelArgs a)
     const int tail2_rows = 2 * tail2_lpi <= cmp_words ? (64 * tail2_recip) >> 16 : 0;
     const uint32_t nullword = (uint32_t)NULLJ * 0x01010101u;     // a map word of unmatched SSEs
     SAT_PHASE_INIT;
-#ifdef SAT_EXP_PERTURB
-    uint32_t pert[4] = { (uint32_t)lane_id, 1u, 2u, 3u };
-#endif
+    SAT_DIAG_PERTURB_INIT;
     for (int restart = tid; restart < a.maxstart; restart += T) {
         any = true;
         SAT_PHASE(7);
@@ -815,11 +832,7 @@ sat_sa_kernel(const SatKernelArgs a)
 
         // ---- full score of the initial map (tmscord, K.cu:396-440): pairs i < k, both matched
         int score = 0;
-#ifdef SAT_FULLSCORE_ROWS
-        constexpr bool FS_PAIRS = false;                   // diagnostic builds: the rows-in-step form everywhere
-#else
-        constexpr bool FS_PAIRS = N1P > 16;
-#endif
+        constexpr bool FS_PAIRS = N1P > 16 && !SAT_DIAG_FS_ROWS_ONLY;
         // The pair walk below costs the wave what its busiest lane costs, m (m - 1) / 2 single pairs for m matched
         // SSEs (~27 instructions each), the rows-in-step form n1w * n1 / 2 packed evaluations (~31 each) whatever
         // the maps hold: a wave whose densest initial map would make the walk the dearer of the two takes the rows
@@ -907,33 +920,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 score += rowsum;
             }
         } else {
-        // rows in step: every lane walks all n1 rows of its chain, the wave reads the query cells with scalar loads
-        for (int i = 0; i < n1 - 1; i++) {
-            // an unmatched SSE has no row in LDS: its lane walks row 0 and drops the sum
-            const int j = smap_b[map_byte_addr(i)];
-            const bool jreal = j != NULLJ;
-            const DbRow<SPLIT> drow = db_row(jreal ? j : 0);
-            int rowsum = 0;
-            auto row_group = [&](int kw) {
-                // pairs with k <= i inside the first word are switched off (mask from i and kw)
-                const int below = i + 1 - 4 * kw;
-                const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
-                const uint32_t qi = (uint32_t)(kw * N1P + i);
-                rowsum = quad_terms(load_qdist(qi << 4), load_qcode(qi << 2), drow, smap[kw * TP + tid], force, rowsum);
-            };
-            // one lane per chain: the group index stays in scalar registers, and so do the query cells
-            if (lpc == 1) {
-                for (int kw = (i + 1) >> 2; kw < n1w; kw++) {
-                    const int below = i + 1 - 4 * kw;
-                    const uint32_t force = below <= 0 ? 0u : (0x04040404u >> (8 * (4 - below)));
-                    const uint32_t qi = (uint32_t)(kw * N1P + i);
-                    rowsum = quad_terms(load_qdist_uniform(qi), load_qcode_uniform(qi), drow, smap[kw * TP + tid], force, rowsum);
-                }
-            } else {
-                for (int kw = ((i + 1) >> 2) + part; kw < n1w; kw += lpc) row_group(kw);
-            }
-            score += jreal ? rowsum : 0;
-        }
+            score = score_rows();
         }
         if (lpc >= 2) score += __shfl_xor(score, 1, 64);
         if (lpc == 4) score += __shfl_xor(score, 2, 64);
@@ -973,9 +960,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 blk.y = blk.w;
             }
             const uint32_t word_a = blk.x, word_b = blk.y;
-#ifdef SAT_EXP_PERTURB
-            satk::perturb(pert);
-#endif
+            SAT_DIAG_PERTURB_STEP;
 
             // which query SSE moves (K.cu:1037-1042)
             const int ssei = scaled_index16(word_a >> 16, n1, n1 - 1);
@@ -1006,9 +991,7 @@ sat_sa_kernel(const SatKernelArgs a)
                     p = none ? 0 : p;
                 }
                 const int A = smap_b[map_byte_addr(p)];
-#if defined(SAT_DUP) && SAT_DUP == 4
-                (void)*(const volatile __attribute__((address_space(3))) uint8_t *)&smap_b[map_byte_addr(p)];   // diagnostic: own-map byte read twice
-#endif
+                SAT_DIAG_DUP_MAPBYTE(&smap_b[map_byte_addr(p)]);
                 oldj = p == ssei ? A : NULLJ;
                 const uint32_t above = 0xFFFFFFFEu << (A & 31);          // bits A+1 .. 31
                 const uint32_t y = occ.w[0] & above;                     // occupied above A
@@ -1123,9 +1106,7 @@ sat_sa_kernel(const SatKernelArgs a)
                                 // are padding: unmatched SSEs against the query's sentinel cells
                                 const int kwu = rkw + u * lpi;
                                 wd[u] = smap[kwu * TP + owner];
-#if defined(SAT_DUP) && SAT_DUP == 2
-                                (void)*(const volatile __attribute__((address_space(3))) uint32_t *)&smap[kwu * TP + owner];   // diagnostic: map word read twice
-#endif
+                                SAT_DIAG_DUP_MAPWORD(&smap[kwu * TP + owner]);
                                 qd[u] = load_qdist(qoff16 + (uint32_t)(u * lpi * N1P * 16));
                                 qc[u] = load_qcode(qoff4 + (uint32_t)(u * lpi * N1P * 4));
                             }
@@ -1143,10 +1124,7 @@ sat_sa_kernel(const SatKernelArgs a)
                         }
                         if (ok)
                             __hip_atomic_fetch_add((lds_i32_t *)(items + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#if defined(SAT_DUP) && SAT_DUP == 3
-                        if (ok)                                                          // diagnostic: a second atomic (adds 0)
-                            __hip_atomic_fetch_add((lds_i32_t *)(items + idx), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#endif
+                        if (ok) SAT_DIAG_DUP_ATOMIC((lds_i32_t *)(items + idx));
                     };
                     auto main_round = [&](int first) {
                         if constexpr (WPL > 0) one_round(std::integral_constant<int, WPL>{}, first, cmp_lpi, sub, kw, lane_ok);
@@ -1211,6 +1189,7 @@ sat_sa_kernel(const SatKernelArgs a)
             }
             const int newscore = score + delta;
             SAT_PHASE(3);                 // read-back (compacted) or the static loops
+            SAT_DIAG_SELFCHECK_STEP;
 
             // best-so-far from the PROPOSED state, before the accept test (K.cu:1136-1155)
             // (which restart holds the best is settled once per restart, below the step loop)
@@ -1272,9 +1251,7 @@ sat_sa_kernel(const SatKernelArgs a)
         if (best > best_before) best_restart = (uint32_t)restart;
     }
     SAT_PHASE_FLUSH;
-#ifdef SAT_EXP_PERTURB
-    if ((pert[0] ^ pert[1] ^ pert[2] ^ pert[3]) == 0xDEADBEEFu) Q.scores[e] = -1;
-#endif
+    SAT_DIAG_PERTURB_END;
 
     // ---- arg-max over restarts; ties go to the lowest restart index, which is the
     // first restart that reaches the maximum in the reference's sequential order

@@ -12,18 +12,7 @@
  * device memory.  Threading: one context per host thread; no globals.
  * Errors: every int-returning call yields 0 on success and a negative SAT_E*
  * code otherwise; sat_last_error() has the text.  Nothing in the library calls
- * exit() or abort().  Environment (tuning / test overrides of launch heuristics, results do
- * not depend on them; read ONCE by sat_ctx_create, never on the search path):
- * SAT_EXP_LPC = 0|1|2 (log2 lanes per chain), SAT_EXP_COMPACT = 0|1
- * (wave-level work compaction), SAT_EXP_QLDS = 0|1 (query cells staged in LDS),
- * SAT_EXP_LDS_PAD = bytes (unused LDS added per db entry: occupancy experiments),
- * SAT_EXP_EPW = 1..8 (db entries per workgroup; default: chosen per launch from the CU's LDS granules),
- * SAT_EXP_LPC_WAVES = n (resident waves per CU at which the lanes-per-chain choice stops adding lanes, default 8),
- * SAT_EXP_GENERAL = 1 (run the general kernel instantiation instead of the option-specialised ones),
- * SAT_EXP_STREAMS = 0 (queue the order buckets of a search one after the other instead of
- * concurrently on side streams), SAT_EXP_UPLOAD_THREADS = n (host threads slicing the database
- * copy, default 4), SAT_EXP_UPLOAD_TIMING = 1 (per-phase upload times on stderr),
- * SAT_EXP_UPLOAD_PIECES = n (pieces of the overlapped upload + search, default by size, at most 8).
+ * exit() or abort().  (Tuning / test overrides of the launch heuristics: include/satabsearch_debug.h.)
  * There is no CPU fallback: without a usable HIP device sat_ctx_create() fails with
  * SAT_ENODEVICE.
  */

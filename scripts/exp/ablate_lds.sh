@@ -1,6 +1,6 @@
 #!/bin/bash
 # scripts/exp/ablate_lds.sh - which LDS access site makes the bank conflicts of the bench kernel?
-# Builds diagnostic variants of the device library in which ONE access site is issued twice (SAT_DUP =
+# Builds diagnostic variants of the device library in which ONE access site is issued twice (-DSAT_DIAG_DUP =
 # 1: the db-cell gathers of the pair evaluation, 2: the chain-map words of the rounds, 3: the item
 # accumulator atomics, 4: the own-map byte read of the proposal; volatile duplicates, results
 # unchanged) and, on the GPU box, collects SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS and
@@ -11,7 +11,7 @@
 set -uo pipefail
 repo=$(cd "$(dirname "$0")/../.." && pwd)
 if [ "${1:-}" = build ]; then
-  for k in 1 2 3 4; do bash $repo/scripts/exp/variant_lib.sh abl$k -DSAT_DUP=$k & done; wait
+  for k in 1 2 3 4; do bash $repo/scripts/exp/variant_lib.sh abl$k -DSAT_DIAG -DSAT_DIAG_DUP=$k & done; wait
   exit 0
 fi
 out=$repo/gpurun_out/ablate_lds.txt; : > $out

@@ -1,4 +1,4 @@
-"""Randomized GPU-vs-oracle parity soak (not part of the test suite): many random databases,
+"""Randomized GPU-vs-oracle parity soak (30 s of it with a fixed seed run inside the suite, tests/test_gpu_parity.py): many random databases,
 queries, option combinations and restart counts; stops at the first mismatch."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -662,6 +662,56 @@ def test_overlapped_upload_rejects_what_the_plain_upload_rejects(monkeypatch):
         assert np.array_equal(got, want)
 
 
+# ---------------------------------------------------------------- randomized soak, time-boxed
+def test_randomized_soak_with_a_fixed_seed():
+    """scripts/fuzz_parity.py inside the suite: 30 seconds of random databases (1..111 SSEs, '?' codes, exact 4.0 A
+    differences), planted queries, LORDER / LSOLN, restart counts 1..300, forced lanes per chain / compaction / entries
+    per workgroup and best-k rows, from a fixed seed - GPU against the oracle, bit for bit; stops at the first mismatch.
+    (Longer soaks of other seeds are run by hand, profiles/*_logs/fuzz_*.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SAT_EXP_")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "30", "20251005"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    last = p.stdout.strip().splitlines()[-1]
+    assert last.startswith("fuzz ok:"), last
+    assert int(last.split()[2]) >= 50, last          # ~10 cases a second on an idle box
+    print("\n" + last)
+
+
+# ---------------------------------------------------------------- the reference's in-kernel self-check
+@pytest.mark.parametrize("lpc", ["", "1", "2"])
+def test_every_move_passes_the_references_self_check(lpc):
+    """The reference kernel, built with TESTING, asserts on EVERY move that score + delta equals the full score of
+    the moved map (K.cu:1105-1134).  The same assertion lives in a diagnostic build of the device library
+    (tests/native/libsat_selfcheck.so = the product sources + -DSAT_DIAG_SELFCHECK, csrc/diag/sat_diag.hpp; the
+    shipped library contains none of it): after every proposal the proposed map's score is recomputed from the
+    map bytes and the cell matrix and compared with score + delta.  Entries of 1..111 SSEs x queries of every
+    size class x LORDER / LSOLN, one and several lanes per chain: millions of checked moves, no mismatch, and the
+    diagnostic build's scores equal the oracle's."""
+    import json
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "tests", "native", "libsat_selfcheck.so")
+    assert os.path.exists(lib), "build with python -m cuda_satabsearch_amd.build --oracle"
+    env = dict(os.environ, SAT_DEVICE_LIB=lib)
+    if lpc:
+        env["SAT_EXP_LPC"] = lpc
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native", "selfcheck_run.py")], capture_output=True,
+                       text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    cases = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(cases) == 18
+    total = 0
+    for c in cases:
+        assert c["mismatches"] == 0 and c["scores_equal_oracle"], c
+        # every (entry, restart, step) proposes exactly one move: 40 entries x 70 restarts x 100 steps
+        assert c["checks"] == 40 * 70 * 100, c
+        total += c["checks"]
+    print(f"\n{total} moves checked against a full recomputation (lanes per chain: {lpc or 'default'})")
+
+
 # ---------------------------------------------------------------- reference -c stream (T3)
 @pytest.mark.parametrize("job", ["c1_d1ubia_small.r128", "d2phlb1.r4096", "d1twfa_.r128", "d2phlb1_TFT.r128", "multiquery.r128"])
 def test_statistically_consistent_with_reference_host_output(searcher, small_db, golden_dir, job):
