@@ -9,13 +9,16 @@
 // kernel body K.cu:924-1233 (K.cu = nvcc_src_current/cudaSaTabsearch_kernel.cu).
 //
 // Data layout
-//   Dc   (LDS) n2 x (n2+1) 8-byte cells {f32 distance, u32 code byte} of the db
-//        entry, expanded from the packed lower triangle in HBM.  Column n2 is a "null"
+//   Dc   (LDS) the db entry's cells {f32 distance, code byte}.  Entries of up to 32 SSEs: the full
+//        n2 x (n2+1) matrix of 8-byte cells, expanded from the packed lower triangle in HBM (one
+//        ds_read_b64 per pair); larger entries: the lower triangle as it is, distances and codes in two
+//        arrays, addressed by (max, min) of the pair - half the LDS where the cells limit the
+//        workgroups per CU (DbRow).  Column n2 (full matrix) / row n2 (triangle) is a "null"
 //        SSE whose distance is the sentinel -1e30: an unmatched query SSE
 //        is represented as matched to the null SSE, so |d1 - d2| <= 4 is false and the
 //        pair scores 0 without any branch or predicate in the hot loop (the reference
-//        tests l >= 0, old_j >= 0, k != sse_i per pair, K.cu:521-531).  The null SSE has no
-//        ROW: a null image contributes 0, the compacted rounds never list it, and the two
+//        tests l >= 0, old_j >= 0, k != sse_i per pair, K.cu:521-531).  The null SSE is never the
+//        ROW of an evaluation: a null image contributes 0, the compacted rounds never list it, and the two
 //        loops that may meet one (full score, static loops) walk row 0 and drop the sum.
 //   Q    query, grouped by 4 consecutive query SSEs k (one "word" of the map) and
 //        TRANSPOSED: qdist[kw*N1P + i] = float4 of dmat1[i][4kw..4kw+3],
@@ -133,6 +136,14 @@
 #define SAT_DIAG_SELFCHECK_STEP
 #endif
 
+// split cells (4-byte distances + 1-byte codes) in launches whose db-side bit sets have at least this many words
+#ifndef SAT_SPLIT_FROM_M2W
+#define SAT_SPLIT_FROM_M2W 2
+#endif
+// register budget of the option-specialised kernels with one lane per chain, as resident waves per SIMD
+#ifndef SAT_FAST_WAVES
+#define SAT_FAST_WAVES 6
+#endif
 #define SAT_K_MAXITER 100
 #define SAT_FS_UNROLL 2               // pairs per lane and round of the full score of an initial map
 #define SAT_K_STEP_BLOCK0 32          // Philox block of SA step 0 (oracle/sa_oracle.h)
@@ -312,13 +323,23 @@ template <int W> __device__ __forceinline__ int bits_select(const Bits<W> &b, in
 //   qd, qc   the query group's distances and code bytes for this lane's column
 //   force    0x04 in byte s forces pair s to score 0 (used by the full score for k <= i)
 // Returns acc + sum.  See the file header for the arithmetic.
-// A row of the db entry's cell matrix in LDS.  Entries of up to 32 SSEs keep 8-byte cells
-// {f32 distance, code byte}: one ds_read_b64 per pair.  Larger entries keep the distances and the
-// code bytes in two arrays (5 bytes per cell, two reads per pair): their cells are what limits the
-// workgroups per CU, and 37 % less LDS is worth more there than the extra reads.
+// A row of the db entry's cell matrix in LDS.  Entries of up to 32 SSEs keep the FULL matrix of 8-byte cells
+// {f32 distance, code byte}: one ds_read_b64 per pair at row base + image.  Larger entries - whose cells are what
+// limits the workgroups per CU - keep only the lower TRIANGLE (the matrix is symmetric), distances and code bytes in
+// two arrays (5 bytes per cell, two reads per pair): a 96-SSE entry takes 23.8 KB where the full split matrix took
+// 46.6 KB, i.e. 4-5 resident workgroups per CU instead of 2-3, for ~17 cycles of index arithmetic per pair
+// (tri_index) in kernels that issue a VALU instruction every 5-6 cycles.  The null SSE is row n2 of the triangle
+// (n2 + 1 sentinel cells): an unmatched image l = n2 is the larger index of every pair it appears in.
 template <bool SPLIT> struct DbRow;
 template <> struct DbRow<false> { const uint2 *cells; };
-template <> struct DbRow<true> { const float *dist; const uint8_t *code; };
+template <> struct DbRow<true> { const float *dist; const uint8_t *code; int j; };
+// cell (j, l) of the lower triangle: row max(j, l), column min(j, l)
+__device__ __forceinline__ int tri_index(int j, int l)
+{
+    const int mx = max(j, l), mn = min(j, l);
+    return (int)((__umul24((uint32_t)mx, (uint32_t)mx) + (uint32_t)mx) >> 1) + mn;
+}
+__host__ __device__ inline uint32_t tri_cells(int n2) { return (uint32_t)(n2 + 1) * (uint32_t)(n2 + 2) / 2u; }   // rows 0 .. n2
 
 template <bool SPLIT>
 __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const DbRow<SPLIT> row,
@@ -328,10 +349,12 @@ __device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, co
     uint2 d0, d1, d2, d3;
     SAT_DIAG_DUP_CELLS(row, l0, l1, l2, l3);
     if constexpr (SPLIT) {
-        d0 = uint2{ __float_as_uint(row.dist[l0]), row.code[l0] };
-        d1 = uint2{ __float_as_uint(row.dist[l1]), row.code[l1] };
-        d2 = uint2{ __float_as_uint(row.dist[l2]), row.code[l2] };
-        d3 = uint2{ __float_as_uint(row.dist[l3]), row.code[l3] };
+        const int c0 = tri_index(row.j, (int)l0), c1 = tri_index(row.j, (int)l1), c2 = tri_index(row.j, (int)l2),
+                  c3 = tri_index(row.j, (int)l3);
+        d0 = uint2{ __float_as_uint(row.dist[c0]), row.code[c0] };
+        d1 = uint2{ __float_as_uint(row.dist[c1]), row.code[c1] };
+        d2 = uint2{ __float_as_uint(row.dist[c2]), row.code[c2] };
+        d3 = uint2{ __float_as_uint(row.dist[c3]), row.code[c3] };
     } else {
         d0 = row.cells[l0];
         d1 = row.cells[l1];
@@ -466,12 +489,13 @@ __host__ __device__ inline LdsLayout lds_layout(int m2w, int n2, int words, int 
                                                  bool q_in_lds, bool compact)
 {
     LdsLayout L;
-    const bool split = m2w > 1;
-    // rows 0 .. n2-1 of the cell matrix, columns 0 .. n2: the null SSE (index n2) has a column - map bytes
+    const bool split = m2w >= SAT_SPLIT_FROM_M2W;
+    // full matrix: rows 0 .. n2-1, columns 0 .. n2: the null SSE (index n2) has a column - map bytes
     // of unmatched query SSEs point at it - but no row: a null image scores 0 and its row is never summed
     uint32_t dcells = (uint32_t)n2 * (uint32_t)(n2 + 1);
     uint32_t off;
-    if (split) {                                              // 4-byte distances + 1-byte codes (see DbRow)
+    if (split) {                                              // lower triangle incl. the null row, 4-byte distances + 1-byte codes (see DbRow)
+        dcells = tri_cells(n2);
         dcells = (dcells + 3u) & ~3u;
         L.code = dcells * 4u;
         off = L.code + ((dcells + 15u) & ~15u);
@@ -529,7 +553,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
 // WPL: map words per lane in the compacted rounds (satk::compaction_shape) when every query of
 // the launch has the same; 0 = read it from the query (a four-way switch per step).
 template <int N1P, int M2W, bool QLDS, int OPT, int WPL>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu((OPT < 0 || OPT >= 4) ? 4 : 6)))
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu((OPT < 0 || OPT >= 4) ? 4 : SAT_FAST_WAVES)))
 sat_sa_kernel(const SatKernelArgs a)
 {
     using namespace satk;
@@ -575,13 +599,13 @@ sat_sa_kernel(const SatKernelArgs a)
     const int cmp_words = cmp_lpi * cmp_wpl;                 // words n1w .. cmp_words - 1 stay "unmatched"
     // ---- carve LDS: satk::lds_layout, the function the host sizes the workgroup with.  The cell layout
     // goes by the launch's size class, not by this entry's order (n2max > 32 <=> M2W > 1).
-    constexpr bool SPLIT = M2W > 1;
+    constexpr bool SPLIT = M2W >= SAT_SPLIT_FROM_M2W;
     const LdsLayout lay = lds_layout(M2W, n2, cmp_words, N1P, T, nthreads, QLDS, opt_compact);
     uint2 *Dc = reinterpret_cast<uint2 *>(lds_slot);                          // !SPLIT: 8-byte cells
     float *distL = reinterpret_cast<float *>(lds_slot);                       // SPLIT: distances ...
     uint8_t *codeL = lds_slot + lay.code;                                     // ... and code bytes
     auto db_row = [&](int j) -> DbRow<SPLIT> {
-        if constexpr (SPLIT) return DbRow<true>{ distL + __mul24(j, n2p), codeL + __mul24(j, n2p) };
+        if constexpr (SPLIT) return DbRow<true>{ distL, codeL, j };
         else return DbRow<false>{ Dc + __mul24(j, n2p) };
     };
     // query groups in LDS cover the padding words too (sentinel cells, like every group past n1w)
@@ -666,32 +690,46 @@ sat_sa_kernel(const SatKernelArgs a)
         else return qcodeC[idx];
     };
 
-    // ---- stage the db entry: packed lower triangle (HBM) -> full cell matrix (LDS)
+    SAT_PHASE_INIT;
+    // ---- stage the db entry: packed lower triangle (HBM) -> full cell matrix (LDS).  Row r of the triangle (r + 1
+    // cells) and row n2 - 1 - r (n2 - r cells) are n2 + 1 cells together: the waves take such row pairs in turn
+    // and the lanes the n2 + 1 positions, so consecutive lanes read consecutive triangle cells, every triangle cell
+    // is read ONCE and written to both mirror positions, and no lane divides (the first version walked the
+    // n2 (n2 + 1) cells of the full matrix: a division, and a gather of the mirrored triangle cell, per cell).
+    // Entries above 32 SSEs keep the triangle as it is (DbRow): a straight copy.
     {
         const uint8_t *tt = a.tab_tri + a.cell_off[e];
         const float *dd = a.dist_tri + a.cell_off[e];
-        const int total = n2 * n2p;
-        for (int c = lane_id; c < total; c += nthreads) {
-            int j = c / n2p;
-            int l = c - j * n2p;
-            uint2 cell;
-            if (l < n2) {
-                int hi = j > l ? j : l, lo = j > l ? l : j;
-                int t = hi * (hi + 1) / 2 + lo;
-                const float v = dd[t];
-                // NaN / inf never pass the reference's |d1 - d2| <= 4 either: same as the sentinel
-                cell.x = __float_as_uint(fabsf(v) <= 3.0e38f ? v : SAT_K_DSENT);
-                cell.y = tt[t];
-            } else {
-                cell.x = __float_as_uint(SAT_K_DSENT);   // the null SSE never passes the distance test
-                cell.y = 0u;
+        // NaN / inf never pass the reference's |d1 - d2| <= 4 either: same as the sentinel
+        auto clean = [](float v) -> uint32_t { return __float_as_uint(fabsf(v) <= 3.0e38f ? v : SAT_K_DSENT); };
+        if constexpr (SPLIT) {
+            // the triangle as it lies in HBM, then the null row: n2 + 1 cells that never pass the distance test
+            const int ncell = (n2 * n2p) >> 1;
+            for (int t = lane_id; t < ncell; t += nthreads) {
+                distL[t] = __uint_as_float(clean(dd[t]));
+                codeL[t] = tt[t];
             }
-            if constexpr (SPLIT) {
-                distL[c] = __uint_as_float(cell.x);
-                codeL[c] = (uint8_t)cell.y;
-            } else {
-                Dc[c] = cell;
+            for (int x = lane_id; x <= n2; x += nthreads) {
+                distL[ncell + x] = SAT_K_DSENT;
+                codeL[ncell + x] = 0;
             }
+        } else {
+            const int swave = lane_id >> 6, swaves = nthreads >> 6;
+            const int pairs = (n2 + 1) >> 1;               // an odd order's middle row pairs with itself: taken once
+            for (int r = swave; r < pairs; r += swaves) {
+                const int rb = n2 - 1 - r;
+                for (int x = wlane; x <= n2; x += 64) {
+                    const bool first = x <= r;
+                    if (!first && rb == r) continue;
+                    const int hi = first ? r : rb, lo = first ? x : x - r - 1;
+                    const int t = ((hi * (hi + 1)) >> 1) + lo;
+                    const uint2 cell = uint2{ clean(dd[t]), tt[t] };
+                    Dc[__mul24(hi, n2p) + lo] = cell;
+                    if (lo != hi) Dc[__mul24(lo, n2p) + hi] = cell;
+                }
+            }
+            // the null SSE's column: never passes the distance test
+            for (int j = lane_id; j < n2; j += nthreads) Dc[__mul24(j, n2p) + n2] = uint2{ __float_as_uint(SAT_K_DSENT), 0u };
         }
         if (lane_id < 4 * TMS) tmask[lane_id] = 0u;
         if (lane_id == 0) *reinterpret_cast<unsigned long long *>(lds_slot + lay.leader) = 0ull;   // LSOLN leader key
@@ -777,7 +815,7 @@ sat_sa_kernel(const SatKernelArgs a)
     const int tail2_recip = (65536 + tail2_lpi - 1) / tail2_lpi;
     const int tail2_rows = 2 * tail2_lpi <= cmp_words ? (64 * tail2_recip) >> 16 : 0;
     const uint32_t nullword = (uint32_t)NULLJ * 0x01010101u;     // a map word of unmatched SSEs
-    SAT_PHASE_INIT;
+    SAT_PHASE(7);                         // staging (and, in the restart loop, its own overhead)
     SAT_DIAG_PERTURB_INIT;
     for (int restart = tid; restart < a.maxstart; restart += T) {
         any = true;
@@ -911,7 +949,7 @@ sat_sa_kernel(const SatKernelArgs a)
 #pragma unroll
                     for (int u = 0; u < SAT_FS_UNROLL; u++) {
                         uint32_t dd, dc;
-                        if constexpr (SPLIT) { dd = __float_as_uint(drow.dist[ll[u]]); dc = drow.code[ll[u]]; }
+                        if constexpr (SPLIT) { const int c = tri_index(drow.j, ll[u]); dd = __float_as_uint(drow.dist[c]); dc = drow.code[c]; }
                         else { const uint2 c = drow.cells[ll[u]]; dd = c.x; dc = c.y; }
                         const int term = pair_term(qcell[u].x, qcell[u].y, dd, dc);
                         rowsum += vv[u] ? term : 0;
