@@ -421,7 +421,11 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
                 const size_t lds_l = satk::lds_bytes(n1max, n1p, n2max, chains, chains << l, lsoln != 0, qlds, compact);
                 if (lds_l > kLdsLimit) break;
                 lpc_shift = l;
-                if (resident_by_lds(lds_l) * ((chains << l) / 64) >= ctx->tune.lpc_waves) break;
+                // (target: 8 resident waves per CU; 12 for the 101-SSE query class, whose steps are the longest
+                // dependent chains - measured with the triangle cells: configs[4] 2.31 -> 2.45 M scorings/s, the
+                // 101-SSE probe 2.48 -> 2.65 M, while 96-SSE entries under a 32-SSE query lose 5 % at 12)
+                const int want_waves = ctx->tune.lpc_waves > 0 ? ctx->tune.lpc_waves : (n1p == 112 ? 12 : 8);
+                if (resident_by_lds(lds_l) * ((chains << l) / 64) >= want_waves) break;
             }
             if (ctx->tune.lpc >= 0 && ctx->tune.lpc <= 2 && (chains << ctx->tune.lpc) <= 1024) lpc_shift = ctx->tune.lpc;
             // the per-wave tables grow with the lanes: re-size, backing off if that no longer fits
@@ -638,7 +642,7 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         ctx->tune.upload_timing = env_int("SAT_EXP_UPLOAD_TIMING", 0);
         ctx->tune.upload_pieces = env_int("SAT_EXP_UPLOAD_PIECES", 0);
         ctx->tune.epw = env_int("SAT_EXP_EPW", 0);
-        ctx->tune.lpc_waves = env_int("SAT_EXP_LPC_WAVES", 8);
+        ctx->tune.lpc_waves = env_int("SAT_EXP_LPC_WAVES", 0);
         const int pad = env_int("SAT_EXP_LDS_PAD", 0);
         ctx->tune.lds_pad = pad > 0 ? (size_t)pad : 0;
         if (ctx->tune.streams != 0) {

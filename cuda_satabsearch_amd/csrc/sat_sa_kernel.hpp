@@ -836,6 +836,11 @@ sat_sa_kernel(const SatKernelArgs a)
             int j = 0;
             bool stopped = false;
             for (int i0 = 0; i0 < n1; i0 += 4) {
+                // a chain whose type search failed draws no more (K.cu:633-638): once that holds for every lane of
+                // the wave the rest of the query is skipped - for long queries against short entries (the scan
+                // position runs off the entry after ~2 n2 query SSEs) that is most of the loop and of its Philox blocks
+                if constexpr (N1P > 32)
+                    if (__builtin_amdgcn_ballot_w64(!stopped) == 0ull) break;
                 uint4 r = philox_block(Q.seed_q, subseq, (uint32_t)(i0 >> 2));
                 uint32_t rv[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll

@@ -66,7 +66,10 @@ def main():
     sums = {}
     for k in range(rounds):
         for l in (libs if k % 2 == 0 else libs[::-1]):
-            env = dict(os.environ, SAT_DEVICE_LIB=os.path.join(ROOT, l))
+            # "lib.so#NAME=value,NAME=value": the same build under launch-heuristic overrides (satabsearch_debug.h)
+            libpath, _, extra = l.partition("#")
+            env = dict(os.environ, SAT_DEVICE_LIB=os.path.join(ROOT, libpath))
+            env.update(dict(kv.split("=", 1) for kv in extra.split(",") if kv))
             p = subprocess.run([sys.executable, child, path, str(int(lorder)), str(int(lsoln)), str(r)], capture_output=True, text=True, env=env)
             if p.returncode != 0:
                 print(l, "FAILED", p.stderr[-500:], flush=True)
