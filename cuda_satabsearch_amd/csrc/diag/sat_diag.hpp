@@ -29,7 +29,7 @@
 #ifdef SAT_DIAG_DUP
 #if SAT_DIAG_DUP == 1
 // every db-cell gather a second time (volatile, result dropped): the LDS counters grow by exactly this site's share
-#define SAT_DIAG_DUP_CELLS(row, l0, l1, l2, l3) do { if constexpr (!SPLIT) {                                              \
+#define SAT_DIAG_DUP_CELLS(row, l0, l1, l2, l3) do { if constexpr (CELLS == SAT_CELLS_FULL8) {                                            \
         typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_vu64;                          \
         const unsigned long long dup0 = *(lds_vu64)&(row).cells[l0], dup1 = *(lds_vu64)&(row).cells[l1],                  \
                                  dup2 = *(lds_vu64)&(row).cells[l2], dup3 = *(lds_vu64)&(row).cells[l3];                  \

@@ -2,15 +2,16 @@
 #include <stdlib.h>
 #include "sat_shard.h"
 
-/* ns per scoring, 32-SSE query, r = 128, one MI355X (scripts/cost_sweep.py at the end of round 2:
- * profiles/r02n_cost_by_order.txt) */
+/* ns per scoring, 32-SSE query, r = 128, one MI355X (scripts/cost_sweep.py in round 3, after the triangle cell
+ * layout for entries above 48 SSEs: profiles/r03_cost_by_order.txt; an entry of 111 SSEs costs 4.4 entries of 32,
+ * where the full cell matrix made it 5.4) */
 static const struct { int order; double ns; } k_cost[] = {
-    { 4, 44.5 }, { 8, 53.4 }, { 12, 62.7 }, { 16, 70.9 }, { 20, 78.4 }, { 24, 82.7 }, { 28, 87.8 }, { 32, 94.1 },
-    { 40, 122.9 }, { 48, 151.7 }, { 56, 185.0 }, { 64, 206.9 }, { 72, 258.4 }, { 80, 305.4 }, { 88, 347.5 },
-    { 96, 364.9 }, { 104, 470.1 }, { 111, 508.1 },
+    { 4, 46.9 }, { 8, 55.1 }, { 12, 62.6 }, { 16, 69.2 }, { 20, 75.9 }, { 24, 80.3 }, { 28, 85.7 }, { 32, 88.9 },
+    { 40, 123.3 }, { 48, 152.1 }, { 56, 181.2 }, { 64, 194.4 }, { 72, 247.0 }, { 80, 271.2 }, { 88, 307.9 }, { 96, 332.7 },
+    { 104, 387.8 }, { 111, 394.0 },
 };
 #define K_COST_N ((int)(sizeof(k_cost) / sizeof(k_cost[0])))
-#define K_COST_UNIT 94.1
+#define K_COST_UNIT 88.9
 
 double sat_entry_cost(int order)
 {

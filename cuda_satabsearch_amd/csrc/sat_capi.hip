@@ -150,11 +150,15 @@ void free_db(sat_ctx *ctx)
 
 typedef void (*kernel_fn)(const SatKernelArgs);
 
-template <int N1P, bool QLDS, int OPT, int WPL> kernel_fn pick_m2w(int m2w)
+// db-side set width and cell layout (satk::cell_layout of the launch's largest entry): one-word sets go with the
+// 8-byte cells, two-word sets with either split layout (entries of up to 48 SSEs: full matrix, above: triangle),
+// four-word sets with the triangle
+template <int N1P, bool QLDS, int OPT, int WPL> kernel_fn pick_m2w(int m2w, int cells)
 {
-    if (m2w == 1) return sat_sa_kernel<N1P, 1, QLDS, OPT, WPL>;
-    if (m2w == 2) return sat_sa_kernel<N1P, 2, QLDS, OPT, WPL>;
-    return sat_sa_kernel<N1P, 4, QLDS, OPT, WPL>;
+    if (m2w == 1) return sat_sa_kernel<N1P, 1, QLDS, OPT, WPL, SAT_CELLS_FULL8>;
+    if (m2w == 2) return cells == SAT_CELLS_FULL5 ? sat_sa_kernel<N1P, 2, QLDS, OPT, WPL, SAT_CELLS_FULL5>
+                                                   : sat_sa_kernel<N1P, 2, QLDS, OPT, WPL, SAT_CELLS_TRI5>;
+    return sat_sa_kernel<N1P, 4, QLDS, OPT, WPL, SAT_CELLS_TRI5>;
 }
 
 // opt >= 0: an instantiation with the options as compile-time facts (bit 0 LORDER, bit 1 LSOLN; one
@@ -163,19 +167,19 @@ template <int N1P, bool QLDS, int OPT, int WPL> kernel_fn pick_m2w(int m2w)
 // kernel's OPT and WPL parameters).  These exist for the default placement of the query cells only (LDS for the
 // 16 class, L1/L2 for the others) and for the wpl values a class can have
 // (satk::compaction_shape); anything else runs the general instantiation.
-template <int N1P, int OPT> kernel_fn pick_wpl(int m2w, int wpl)
+template <int N1P, int OPT> kernel_fn pick_wpl(int m2w, int cells, int wpl)
 {
     constexpr bool kQ = N1P < 32;
-    if constexpr ((OPT & 1) == 0) return pick_m2w<N1P, kQ, OPT, 0>(m2w);     // no compaction: wpl unused
+    if constexpr ((OPT & 1) == 0) return pick_m2w<N1P, kQ, OPT, 0>(m2w, cells);     // no compaction: wpl unused
     else {
-        if (wpl == 4) return pick_m2w<N1P, kQ, OPT, 4>(m2w);
+        if (wpl == 4) return pick_m2w<N1P, kQ, OPT, 4>(m2w, cells);
         if constexpr (N1P <= 64)
-            if (wpl == 3) return pick_m2w<N1P, kQ, OPT, 3>(m2w);
+            if (wpl == 3) return pick_m2w<N1P, kQ, OPT, 3>(m2w, cells);
         if constexpr (N1P == 16) {
-            if (wpl == 2) return pick_m2w<N1P, kQ, OPT, 2>(m2w);
-            if (wpl == 1) return pick_m2w<N1P, kQ, OPT, 1>(m2w);
+            if (wpl == 2) return pick_m2w<N1P, kQ, OPT, 2>(m2w, cells);
+            if (wpl == 1) return pick_m2w<N1P, kQ, OPT, 1>(m2w, cells);
         }
-        return pick_m2w<N1P, kQ, OPT, 0>(m2w);       // queries of different shapes: wpl read per query
+        return pick_m2w<N1P, kQ, OPT, 0>(m2w, cells);       // queries of different shapes: wpl read per query
     }
 }
 
@@ -184,41 +188,41 @@ template <int N1P, int OPT> kernel_fn pick_wpl(int m2w, int wpl)
 template <int N1P, bool QLDS> kernel_fn pick_lpc(int opt)
 {
     switch (opt) {
-    case 4: return sat_sa_kernel<N1P, 4, QLDS, 4, 0>;
-    case 5: return sat_sa_kernel<N1P, 4, QLDS, 5, 0>;
-    case 6: return sat_sa_kernel<N1P, 4, QLDS, 6, 0>;
-    case 7: return sat_sa_kernel<N1P, 4, QLDS, 7, 0>;
-    case 8: return sat_sa_kernel<N1P, 4, QLDS, 8, 0>;
-    case 9: return sat_sa_kernel<N1P, 4, QLDS, 9, 0>;
-    case 10: return sat_sa_kernel<N1P, 4, QLDS, 10, 0>;
-    default: return sat_sa_kernel<N1P, 4, QLDS, 11, 0>;
+    case 4: return sat_sa_kernel<N1P, 4, QLDS, 4, 0, SAT_CELLS_TRI5>;
+    case 5: return sat_sa_kernel<N1P, 4, QLDS, 5, 0, SAT_CELLS_TRI5>;
+    case 6: return sat_sa_kernel<N1P, 4, QLDS, 6, 0, SAT_CELLS_TRI5>;
+    case 7: return sat_sa_kernel<N1P, 4, QLDS, 7, 0, SAT_CELLS_TRI5>;
+    case 8: return sat_sa_kernel<N1P, 4, QLDS, 8, 0, SAT_CELLS_TRI5>;
+    case 9: return sat_sa_kernel<N1P, 4, QLDS, 9, 0, SAT_CELLS_TRI5>;
+    case 10: return sat_sa_kernel<N1P, 4, QLDS, 10, 0, SAT_CELLS_TRI5>;
+    default: return sat_sa_kernel<N1P, 4, QLDS, 11, 0, SAT_CELLS_TRI5>;
     }
 }
 
-template <int N1P> kernel_fn pick_n1p(int m2w, bool qlds, int opt, int wpl)
+template <int N1P> kernel_fn pick_n1p(int m2w, int cells, bool qlds, int opt, int wpl)
 {
     constexpr bool kQ = N1P < 32;
     kernel_fn fn = nullptr;
     if (opt >= 4 && qlds == kQ && m2w == 4) return pick_lpc<N1P, kQ>(opt);
     if (opt >= 0 && opt < 4 && qlds == kQ) {
         switch (opt) {
-        case 0: fn = pick_wpl<N1P, 0>(m2w, wpl); break;
-        case 1: fn = pick_wpl<N1P, 1>(m2w, wpl); break;
-        case 2: fn = pick_wpl<N1P, 2>(m2w, wpl); break;
-        default: fn = pick_wpl<N1P, 3>(m2w, wpl); break;
+        case 0: fn = pick_wpl<N1P, 0>(m2w, cells, wpl); break;
+        case 1: fn = pick_wpl<N1P, 1>(m2w, cells, wpl); break;
+        case 2: fn = pick_wpl<N1P, 2>(m2w, cells, wpl); break;
+        default: fn = pick_wpl<N1P, 3>(m2w, cells, wpl); break;
         }
     }
     if (fn) return fn;
-    return qlds ? pick_m2w<N1P, true, -1, 0>(m2w) : pick_m2w<N1P, false, -1, 0>(m2w);
+    return qlds ? pick_m2w<N1P, true, -1, 0>(m2w, cells) : pick_m2w<N1P, false, -1, 0>(m2w, cells);
 }
 
-kernel_fn pick_kernel(int n1p, int m2w, bool qlds, int opt, int wpl)
+kernel_fn pick_kernel(int n1p, int m2w, int cells, bool qlds, int opt, int wpl)
 {
     switch (n1p) {
-    case 16: return pick_n1p<16>(m2w, qlds, opt, wpl);
-    case 32: return pick_n1p<32>(m2w, qlds, opt, wpl);
-    case 64: return pick_n1p<64>(m2w, qlds, opt, wpl);
-    default: return pick_n1p<112>(m2w, qlds, opt, wpl);
+    case 16: return pick_n1p<16>(m2w, cells, qlds, opt, wpl);
+    case 32: return pick_n1p<32>(m2w, cells, qlds, opt, wpl);
+    case 64: return pick_n1p<64>(m2w, cells, qlds, opt, wpl);
+    default: return pick_n1p<112>(m2w, cells, qlds, opt, wpl);
     }
 }
 
@@ -361,7 +365,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
 
     struct Planned {
         kernel_fn fn; SatKernelArgs args; int count, nqc, threads, n2max, max_entries, epw; size_t lds, slab_words;
-        int n1p, m2w, qlds, opt, wpl;            // the instantiation's template arguments (sat_last_launch_info)
+        int n1p, m2w, qlds, opt, wpl, cells;     // the instantiation's template arguments (sat_last_launch_info)
     };
     std::vector<Planned> plan;
     for (int c = 0; c < 4; c++) {
@@ -386,6 +390,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             }
             if (count == 0) continue;
             const int m2w = n2max <= 32 ? 1 : (n2max <= 64 ? 2 : 4);
+            const int cells = satk::cell_layout(n2max);           // (lds_bytes sizes the workgroup for the same layout)
 
             // chains: one per restart up to 256; shrink until the workgroup fits the LDS.
             // query cells: through L1/L2 for 32-SSE-class queries and up (frees 8+ KB of LDS per
@@ -441,7 +446,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             // option-specialised instantiation when the layout is the default one for these options
             const bool special = (lpc_shift == 0 || m2w == 4) && compact == (lorder != 0) && !ctx->tune.general;
             const int opt = special ? (lorder ? 1 : 0) | (lsoln ? 2 : 0) | (lpc_shift << 2) : -1;
-            kernel_fn fn = pick_kernel(n1p, m2w, qlds, opt, ctx->class_wpl[c]);
+            kernel_fn fn = pick_kernel(n1p, m2w, cells, qlds, opt, ctx->class_wpl[c]);
             if (!fn) return fail(SAT_EDEVICE, "no kernel variant for n1p=%d m2w=%d", n1p, m2w);
             if (ctx->lds_attr_done.insert(reinterpret_cast<const void *>(fn)).second)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
@@ -473,6 +478,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             pl.slab_words = lsoln ? (size_t)((n1max + 3) / 4) * chains : 0;
             pl.n1p = n1p;
             pl.m2w = m2w;
+            pl.cells = cells;
             pl.qlds = qlds ? 1 : 0;
             pl.opt = opt;
             // the words-per-lane argument as pick_kernel resolves it (0 = read per query)
@@ -552,8 +558,8 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
     ctx->last_launch_info.clear();
     for (size_t i = 0; i < plan.size(); i++) {
         char buf[160];
-        snprintf(buf, sizeof buf, "%ssat_sa_kernel<%d, %d, %s, %d, %d> grid %d x %d block %d x %d lds %zu", i ? "; " : "", plan[i].n1p,
-                 plan[i].m2w, plan[i].qlds ? "true" : "false", plan[i].opt, plan[i].wpl,
+        snprintf(buf, sizeof buf, "%ssat_sa_kernel<%d, %d, %s, %d, %d, %d> grid %d x %d block %d x %d lds %zu", i ? "; " : "", plan[i].n1p,
+                 plan[i].m2w, plan[i].qlds ? "true" : "false", plan[i].opt, plan[i].wpl, plan[i].cells,
                  (plan[i].count + plan[i].epw - 1) / plan[i].epw, plan[i].nqc, plan[i].epw, plan[i].threads, plan[i].lds);
         ctx->last_launch_info += buf;
     }
@@ -1120,7 +1126,11 @@ const char *sat_last_launch_info(const sat_ctx *ctx) { return ctx ? ctx->last_la
 void sat_debug_lds_layout(int m2w, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,
                           uint32_t out[11])
 {
-    const satk::LdsLayout L = satk::lds_layout(m2w, n2, satk::map_words((n1 + 3) >> 2), n1p, chains, threads,
+    // m2w: low byte = words of a db-side set; bits 8-9 = 1 + cell layout (SAT_CELLS_*), 0 = the layout launches of
+    // such entries get (satk::cell_layout)
+    const int cells = (m2w >> 8) ? ((m2w >> 8) & 3) - 1 : satk::cell_layout(n2);
+    m2w &= 0xFF;
+    const satk::LdsLayout L = satk::lds_layout(m2w, cells, n2, satk::map_words((n1 + 3) >> 2), n1p, chains, threads,
                                                q_in_lds != 0, compact != 0);
     const uint32_t v[11] = { L.code, L.qdist, L.qcode, L.smap, L.tmask, L.qtypes, L.leader, L.red, L.red_stride, L.items, L.total };
     for (int i = 0; i < 11; i++) out[i] = v[i];

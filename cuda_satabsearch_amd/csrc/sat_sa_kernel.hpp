@@ -136,10 +136,10 @@
 #define SAT_DIAG_SELFCHECK_STEP
 #endif
 
-// split cells (4-byte distances + 1-byte codes) in launches whose db-side bit sets have at least this many words
-#ifndef SAT_SPLIT_FROM_M2W
-#define SAT_SPLIT_FROM_M2W 2
-#endif
+// Cell layouts of a launch, chosen from its largest entry (satk::cell_layout)
+#define SAT_CELLS_FULL8 0             // full matrix, 8-byte cells {f32 distance, code}
+#define SAT_CELLS_FULL5 1             // full matrix, distances and code bytes in two arrays
+#define SAT_CELLS_TRI5  2             // lower triangle, distances and code bytes in two arrays
 // register budget of the option-specialised kernels with one lane per chain, as resident waves per SIMD
 #ifndef SAT_FAST_WAVES
 #define SAT_FAST_WAVES 6
@@ -323,16 +323,24 @@ template <int W> __device__ __forceinline__ int bits_select(const Bits<W> &b, in
 //   qd, qc   the query group's distances and code bytes for this lane's column
 //   force    0x04 in byte s forces pair s to score 0 (used by the full score for k <= i)
 // Returns acc + sum.  See the file header for the arithmetic.
-// A row of the db entry's cell matrix in LDS.  Entries of up to 32 SSEs keep the FULL matrix of 8-byte cells
-// {f32 distance, code byte}: one ds_read_b64 per pair at row base + image.  Larger entries - whose cells are what
-// limits the workgroups per CU - keep only the lower TRIANGLE (the matrix is symmetric), distances and code bytes in
-// two arrays (5 bytes per cell, two reads per pair): a 96-SSE entry takes 23.8 KB where the full split matrix took
-// 46.6 KB, i.e. 4-5 resident workgroups per CU instead of 2-3, for ~17 cycles of index arithmetic per pair
-// (tri_index) in kernels that issue a VALU instruction every 5-6 cycles.  The null SSE is row n2 of the triangle
-// (n2 + 1 sentinel cells): an unmatched image l = n2 is the larger index of every pair it appears in.
-template <bool SPLIT> struct DbRow;
-template <> struct DbRow<false> { const uint2 *cells; };
-template <> struct DbRow<true> { const float *dist; const uint8_t *code; int j; };
+// A row of the db entry's cell matrix in LDS, in one of three layouts picked per LAUNCH from its largest entry
+// (cell_layout):
+//   FULL8  entries of up to 32 SSEs: the full matrix of 8-byte cells {f32 distance, code byte}, one ds_read_b64 per
+//          pair at row base + image;
+//   FULL5  up to 48 SSEs: the full matrix, distances and code bytes in two arrays (5 bytes per cell, two reads per
+//          pair): 37 % less LDS where the cells start to limit the workgroups per CU;
+//   TRI5   above 48 SSEs: only the lower TRIANGLE (the matrix is symmetric), two arrays: a 96-SSE entry takes 23.8 KB
+//          where the full split matrix took 46.6 KB, i.e. 4-5 resident workgroups per CU instead of 2-3, for ~17 cycles
+//          of index arithmetic per pair (tri_index).  Measured per entry order (profiles/r03_cost_by_order.txt): the
+//          triangle loses 10-19 % at 40 and 48 SSEs, where the LDS does not limit the occupancy and the index
+//          arithmetic is pure cost, and wins from 56 SSEs on (-5 % at 64, -12 % at 88, -21 % at 111 under a 32-SSE
+//          query; up to -44 % under an 8-SSE query).  The null SSE is row n2 of the triangle (n2 + 1 sentinel
+//          cells): an unmatched image l = n2 is the larger index of every pair it appears in.
+template <int CELLS> struct DbRow;
+template <> struct DbRow<SAT_CELLS_FULL8> { const uint2 *cells; };
+template <> struct DbRow<SAT_CELLS_FULL5> { const float *dist; const uint8_t *code; };
+template <> struct DbRow<SAT_CELLS_TRI5> { const float *dist; const uint8_t *code; int j; };
+__host__ __device__ inline int cell_layout(int n2max) { return n2max <= 32 ? SAT_CELLS_FULL8 : (n2max <= 48 ? SAT_CELLS_FULL5 : SAT_CELLS_TRI5); }
 // cell (j, l) of the lower triangle: row max(j, l), column min(j, l)
 __device__ __forceinline__ int tri_index(int j, int l)
 {
@@ -340,27 +348,22 @@ __device__ __forceinline__ int tri_index(int j, int l)
     return (int)((__umul24((uint32_t)mx, (uint32_t)mx) + (uint32_t)mx) >> 1) + mn;
 }
 __host__ __device__ inline uint32_t tri_cells(int n2) { return (uint32_t)(n2 + 1) * (uint32_t)(n2 + 2) / 2u; }   // rows 0 .. n2
+// the distance bits and the code byte of cell (row, l)
+template <int CELLS> __device__ __forceinline__ uint2 db_cell(const DbRow<CELLS> row, int l)
+{
+    if constexpr (CELLS == SAT_CELLS_FULL8) return row.cells[l];
+    else if constexpr (CELLS == SAT_CELLS_FULL5) return uint2{ __float_as_uint(row.dist[l]), row.code[l] };
+    else { const int c = tri_index(row.j, l); return uint2{ __float_as_uint(row.dist[c]), row.code[c] }; }
+}
 
-template <bool SPLIT>
-__device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const DbRow<SPLIT> row,
+template <int CELLS>
+__device__ __forceinline__ int quad_terms(const float4 qd, const uint32_t qc, const DbRow<CELLS> row,
                                           const uint32_t word, const uint32_t force, const int acc)
 {
     const uint32_t l0 = word & 0xFFu, l1 = (word >> 8) & 0xFFu, l2 = (word >> 16) & 0xFFu, l3 = word >> 24;
-    uint2 d0, d1, d2, d3;
     SAT_DIAG_DUP_CELLS(row, l0, l1, l2, l3);
-    if constexpr (SPLIT) {
-        const int c0 = tri_index(row.j, (int)l0), c1 = tri_index(row.j, (int)l1), c2 = tri_index(row.j, (int)l2),
-                  c3 = tri_index(row.j, (int)l3);
-        d0 = uint2{ __float_as_uint(row.dist[c0]), row.code[c0] };
-        d1 = uint2{ __float_as_uint(row.dist[c1]), row.code[c1] };
-        d2 = uint2{ __float_as_uint(row.dist[c2]), row.code[c2] };
-        d3 = uint2{ __float_as_uint(row.dist[c3]), row.code[c3] };
-    } else {
-        d0 = row.cells[l0];
-        d1 = row.cells[l1];
-        d2 = row.cells[l2];
-        d3 = row.cells[l3];
-    }
+    const uint2 d0 = db_cell<CELLS>(row, (int)l0), d1 = db_cell<CELLS>(row, (int)l1), d2 = db_cell<CELLS>(row, (int)l2),
+                d3 = db_cell<CELLS>(row, (int)l3);
     // sign bit of t = "distances differ by more than 4 A"
     const float t0 = 4.0f - fabsf(qd.x - __uint_as_float(d0.x));
     const float t1 = 4.0f - fabsf(qd.y - __uint_as_float(d1.x));
@@ -483,19 +486,19 @@ struct LdsLayout {
     uint32_t items;       // per-wave item tables of the work compaction
     uint32_t total;
 };
-// m2w = 32-bit words of a db-side bit set in this launch's size class (1, 2 or 4); the cells are split
-// (4-byte distances + 1-byte codes) exactly when m2w > 1.
-__host__ __device__ inline LdsLayout lds_layout(int m2w, int n2, int words, int n1p, int chains, int threads,
+// m2w = 32-bit words of a db-side bit set in this launch's size class (1, 2 or 4); cells = its cell layout
+// (SAT_CELLS_*: DbRow).
+__host__ __device__ inline LdsLayout lds_layout(int m2w, int cells, int n2, int words, int n1p, int chains, int threads,
                                                  bool q_in_lds, bool compact)
 {
     LdsLayout L;
-    const bool split = m2w >= SAT_SPLIT_FROM_M2W;
+    const bool split = cells != SAT_CELLS_FULL8;
     // full matrix: rows 0 .. n2-1, columns 0 .. n2: the null SSE (index n2) has a column - map bytes
     // of unmatched query SSEs point at it - but no row: a null image scores 0 and its row is never summed
     uint32_t dcells = (uint32_t)n2 * (uint32_t)(n2 + 1);
     uint32_t off;
-    if (split) {                                              // lower triangle incl. the null row, 4-byte distances + 1-byte codes (see DbRow)
-        dcells = tri_cells(n2);
+    if (split) {                                              // 4-byte distances + 1-byte codes; TRI5: lower triangle incl. the null row
+        if (cells == SAT_CELLS_TRI5) dcells = tri_cells(n2);
         dcells = (dcells + 3u) & ~3u;
         L.code = dcells * 4u;
         off = L.code + ((dcells + 15u) & ~15u);
@@ -536,7 +539,7 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
                                              bool compact)
 {
     (void)lsoln;                                              // the best maps live in global memory
-    return lds_layout(n2 <= 32 ? 1 : (n2 <= 64 ? 2 : 4), n2, map_words((n1 + 3) >> 2), n1p, chains, threads, q_in_lds, compact).total;
+    return lds_layout(n2 <= 32 ? 1 : (n2 <= 64 ? 2 : 4), cell_layout(n2), n2, map_words((n1 + 3) >> 2), n1p, chains, threads, q_in_lds, compact).total;
 }
 
 }  // namespace satk
@@ -552,7 +555,8 @@ __host__ __device__ inline size_t lds_bytes(int n1, int n1p, int n2, int chains,
 // step loop (the general kernel spills ~90 SGPRs and is ~9 % slower on the bench shape).
 // WPL: map words per lane in the compacted rounds (satk::compaction_shape) when every query of
 // the launch has the same; 0 = read it from the query (a four-way switch per step).
-template <int N1P, int M2W, bool QLDS, int OPT, int WPL>
+// CELLS: the launch's cell layout (SAT_CELLS_*, satk::cell_layout of its largest entry).
+template <int N1P, int M2W, bool QLDS, int OPT, int WPL, int CELLS>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu((OPT < 0 || OPT >= 4) ? 4 : SAT_FAST_WAVES)))
 sat_sa_kernel(const SatKernelArgs a)
 {
@@ -599,14 +603,15 @@ sat_sa_kernel(const SatKernelArgs a)
     const int cmp_words = cmp_lpi * cmp_wpl;                 // words n1w .. cmp_words - 1 stay "unmatched"
     // ---- carve LDS: satk::lds_layout, the function the host sizes the workgroup with.  The cell layout
     // goes by the launch's size class, not by this entry's order (n2max > 32 <=> M2W > 1).
-    constexpr bool SPLIT = M2W >= SAT_SPLIT_FROM_M2W;
-    const LdsLayout lay = lds_layout(M2W, n2, cmp_words, N1P, T, nthreads, QLDS, opt_compact);
+    constexpr bool SPLIT = CELLS != SAT_CELLS_FULL8;
+    const LdsLayout lay = lds_layout(M2W, CELLS, n2, cmp_words, N1P, T, nthreads, QLDS, opt_compact);
     uint2 *Dc = reinterpret_cast<uint2 *>(lds_slot);                          // !SPLIT: 8-byte cells
     float *distL = reinterpret_cast<float *>(lds_slot);                       // SPLIT: distances ...
     uint8_t *codeL = lds_slot + lay.code;                                     // ... and code bytes
-    auto db_row = [&](int j) -> DbRow<SPLIT> {
-        if constexpr (SPLIT) return DbRow<true>{ distL, codeL, j };
-        else return DbRow<false>{ Dc + __mul24(j, n2p) };
+    auto db_row = [&](int j) -> DbRow<CELLS> {
+        if constexpr (CELLS == SAT_CELLS_TRI5) return DbRow<SAT_CELLS_TRI5>{ distL, codeL, j };
+        else if constexpr (CELLS == SAT_CELLS_FULL5) return DbRow<SAT_CELLS_FULL5>{ distL + __mul24(j, n2p), codeL + __mul24(j, n2p) };
+        else return DbRow<SAT_CELLS_FULL8>{ Dc + __mul24(j, n2p) };
     };
     // query groups in LDS cover the padding words too (sentinel cells, like every group past n1w)
     float4 *qdistL = reinterpret_cast<float4 *>(lds_slot + lay.qdist);
@@ -696,23 +701,25 @@ sat_sa_kernel(const SatKernelArgs a)
     // and the lanes the n2 + 1 positions, so consecutive lanes read consecutive triangle cells, every triangle cell
     // is read ONCE and written to both mirror positions, and no lane divides (the first version walked the
     // n2 (n2 + 1) cells of the full matrix: a division, and a gather of the mirrored triangle cell, per cell).
-    // Entries above 32 SSEs keep the triangle as it is (DbRow): a straight copy.
+    // Launches with the triangle layout (DbRow) keep the triangle as it is: a straight copy.
     {
         const uint8_t *tt = a.tab_tri + a.cell_off[e];
         const float *dd = a.dist_tri + a.cell_off[e];
         // NaN / inf never pass the reference's |d1 - d2| <= 4 either: same as the sentinel
         auto clean = [](float v) -> uint32_t { return __float_as_uint(fabsf(v) <= 3.0e38f ? v : SAT_K_DSENT); };
-        if constexpr (SPLIT) {
+        auto put = [&](int c, uint32_t dist_bits, uint32_t code) {
+            if constexpr (SPLIT) {
+                distL[c] = __uint_as_float(dist_bits);
+                codeL[c] = (uint8_t)code;
+            } else {
+                Dc[c] = uint2{ dist_bits, code };
+            }
+        };
+        if constexpr (CELLS == SAT_CELLS_TRI5) {
             // the triangle as it lies in HBM, then the null row: n2 + 1 cells that never pass the distance test
             const int ncell = (n2 * n2p) >> 1;
-            for (int t = lane_id; t < ncell; t += nthreads) {
-                distL[t] = __uint_as_float(clean(dd[t]));
-                codeL[t] = tt[t];
-            }
-            for (int x = lane_id; x <= n2; x += nthreads) {
-                distL[ncell + x] = SAT_K_DSENT;
-                codeL[ncell + x] = 0;
-            }
+            for (int t = lane_id; t < ncell; t += nthreads) put(t, clean(dd[t]), tt[t]);
+            for (int x = lane_id; x <= n2; x += nthreads) put(ncell + x, __float_as_uint(SAT_K_DSENT), 0u);
         } else {
             const int swave = lane_id >> 6, swaves = nthreads >> 6;
             const int pairs = (n2 + 1) >> 1;               // an odd order's middle row pairs with itself: taken once
@@ -723,13 +730,13 @@ sat_sa_kernel(const SatKernelArgs a)
                     if (!first && rb == r) continue;
                     const int hi = first ? r : rb, lo = first ? x : x - r - 1;
                     const int t = ((hi * (hi + 1)) >> 1) + lo;
-                    const uint2 cell = uint2{ clean(dd[t]), tt[t] };
-                    Dc[__mul24(hi, n2p) + lo] = cell;
-                    if (lo != hi) Dc[__mul24(lo, n2p) + hi] = cell;
+                    const uint32_t dist_bits = clean(dd[t]), code = tt[t];
+                    put(__mul24(hi, n2p) + lo, dist_bits, code);
+                    if (lo != hi) put(__mul24(lo, n2p) + hi, dist_bits, code);
                 }
             }
             // the null SSE's column: never passes the distance test
-            for (int j = lane_id; j < n2; j += nthreads) Dc[__mul24(j, n2p) + n2] = uint2{ __float_as_uint(SAT_K_DSENT), 0u };
+            for (int j = lane_id; j < n2; j += nthreads) put(__mul24(j, n2p) + n2, __float_as_uint(SAT_K_DSENT), 0u);
         }
         if (lane_id < 4 * TMS) tmask[lane_id] = 0u;
         if (lane_id == 0) *reinterpret_cast<unsigned long long *>(lds_slot + lay.leader) = 0ull;   // LSOLN leader key
@@ -769,7 +776,7 @@ sat_sa_kernel(const SatKernelArgs a)
             // an unmatched SSE has no row in LDS: its lane walks row 0 and drops the sum
             const int j = smap_b[map_byte_addr(i)];
             const bool jreal = j != NULLJ;
-            const DbRow<SPLIT> drow = db_row(jreal ? j : 0);
+            const DbRow<CELLS> drow = db_row(jreal ? j : 0);
             int rowsum = 0;
             auto row_group = [&](int kw) {
                 // pairs with k <= i inside the first word are switched off (mask from i and kw)
@@ -921,7 +928,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 int ji;                                                    // (a lane that is done walks row 0, sums nothing)
                 if constexpr (POP_IMAGES) ji = pop(rj, aj);
                 else { ji = smap_b[map_byte_addr(i)]; ji = ai ? ji : 0; }
-                const DbRow<SPLIT> drow = db_row(ji);
+                const DbRow<CELLS> drow = db_row(ji);
                 const uint32_t qrow = (uint32_t)__mul24(i, N1P * 8);
                 Bits<M1W> rk = ri;                                         // the matched SSEs above i ...
                 Bits<M2W> rl = rj;                                         // ... and their images
@@ -953,10 +960,8 @@ sat_sa_kernel(const SatKernelArgs a)
                     }
 #pragma unroll
                     for (int u = 0; u < SAT_FS_UNROLL; u++) {
-                        uint32_t dd, dc;
-                        if constexpr (SPLIT) { const int c = tri_index(drow.j, ll[u]); dd = __float_as_uint(drow.dist[c]); dc = drow.code[c]; }
-                        else { const uint2 c = drow.cells[ll[u]]; dd = c.x; dc = c.y; }
-                        const int term = pair_term(qcell[u].x, qcell[u].y, dd, dc);
+                        const uint2 c = db_cell<CELLS>(drow, ll[u]);
+                        const int term = pair_term(qcell[u].x, qcell[u].y, c.x, c.y);
                         rowsum += vv[u] ? term : 0;
                     }
                 }
@@ -1137,7 +1142,7 @@ sat_sa_kernel(const SatKernelArgs a)
                         if (ok) {
                             const uint32_t it = items[idx];
                             const int row = it & 0xFF, si = (it >> 8) & 0xFF, owner = (it >> 16) & 0xFF;
-                            const DbRow<SPLIT> drow = db_row(row);
+                            const DbRow<CELLS> drow = db_row(row);
                             float4 qd[W];
                             uint32_t qc[W], wd[W];
                             // byte offsets of (word rkw, column si) in the two query arrays; word rkw + u * lpi is
@@ -1213,7 +1218,7 @@ sat_sa_kernel(const SatKernelArgs a)
                 } else {
                     // dense regime: every lane scores its own two rows
                     // (a null image has no row: row 0 stands in and the sum is dropped)
-                    const DbRow<SPLIT> orow = db_row(oreal ? oldj : 0), nrow = db_row(nreal ? newj : 0);
+                    const DbRow<CELLS> orow = db_row(oreal ? oldj : 0), nrow = db_row(nreal ? newj : 0);
                     int sum_new = 0, sum_old = 0;
                     auto move_group = [&](int kw) {
                         const uint32_t word = smap[kw * TP + tid];

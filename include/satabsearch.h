@@ -245,7 +245,9 @@ const char *sat_last_launch_info(const sat_ctx *ctx);
  * the one function both the kernel and the launch sizing use), byte offsets out[0..10] = code bytes,
  * query distances, query codes, chain maps, type masks, query types, LSOLN leader key, the waves'
  * arg-max keys, the byte stride between those keys (256: inside the item tables), item tables, total.
- * m2w = words of a db-side bit set in the launch's size class: 1 (entries up to 32 SSEs), 2 (64) or 4.
+ * m2w = words of a db-side bit set in the launch's size class: 1 (entries up to 32 SSEs), 2 (64) or 4; its bits
+ * 8-9 may name the cell layout, 1 + {0: full matrix of 8-byte cells, 1: full matrix in two arrays, 2: lower
+ * triangle in two arrays} (0: the layout launches of such entries get).
  * Lets tests assert alignment and monotonicity without a GPU.
  */
 void sat_debug_lds_layout(int m2w, int n1, int n1p, int n2, int chains, int threads, int q_in_lds, int compact,

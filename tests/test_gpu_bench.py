@@ -29,7 +29,7 @@ def test_one_gpu_line_carries_the_contract_keys():
     assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1
     assert abs(r["value"] - 20000 * 5 / (r["ms_per_step"] * 5e-3)) < 1e-6 * r["value"]
     assert r["other_regimes"]["all_hit_scorings_per_sec"] > 0 and r["other_regimes"]["planted_query_scorings_per_sec"] > 0
-    assert "sat_sa_kernel<32, 1, false, 1, 4>" in r["roofline"]["kernel"]
+    assert "sat_sa_kernel<32, 1, false, 1, 4, 0>" in r["roofline"]["kernel"]
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

@@ -191,9 +191,10 @@ def test_lds_carve_alignment_and_monotonicity():
                             else:
                                 assert red_stride == 8 and items - red == 16 * 8 and total == items
                             assert red + (waves - 1) * red_stride + 8 <= total
-                        # monotone in n2 within a cell layout, and in n1
-                        for m2w, orders in ((1, range(1, 33)), (2, range(33, 65)), (4, range(65, 112)), (4, range(1, 112))):
-                            totals = [layout(m2w, n1, n1p, n2, chains, threads, qlds, compact)[10] for n2 in orders]
+                        # monotone in n2 within a cell layout (m2w | (1 + layout) << 8: 0 = 8-byte cells of the full
+                        # matrix, 1 = full matrix in two arrays, 2 = lower triangle in two arrays), and in n1
+                        for m2w, cells, orders in ((1, 0, range(1, 33)), (2, 1, range(1, 49)), (2, 2, range(1, 65)), (4, 2, range(1, 112))):
+                            totals = [layout(m2w | (1 + cells) << 8, n1, n1p, n2, chains, threads, qlds, compact)[10] for n2 in orders]
                             assert totals == sorted(totals)
                         totals = [layout(1, k, n1p, 20, chains, threads, qlds, compact)[10] for k in n1s]
                         assert totals == sorted(totals)
