@@ -397,6 +397,7 @@ int launch_search(sat_ctx *ctx, int lorder, int lsoln, int maxstart, hipStream_t
             // workgroup: more resident waves), in LDS for the small class
             int chains = (maxstart + 63) / 64 * 64;
             if (chains > 256) chains = 256;
+            if (ctx->tune.chains >= 64 && ctx->tune.chains < chains) chains = ctx->tune.chains / 64 * 64;
             // work compaction needs sparse maps: with LORDER = F almost every step proposes a real
             // new image, the static loops win and the tables would only cost LDS
             bool compact = lorder != 0;
@@ -649,6 +650,7 @@ sat_ctx *sat_ctx_create(int device, uint64_t seed)
         ctx->tune.upload_pieces = env_int("SAT_EXP_UPLOAD_PIECES", 0);
         ctx->tune.epw = env_int("SAT_EXP_EPW", 0);
         ctx->tune.lpc_waves = env_int("SAT_EXP_LPC_WAVES", 0);
+        ctx->tune.chains = env_int("SAT_EXP_CHAINS", 0);
         const int pad = env_int("SAT_EXP_LDS_PAD", 0);
         ctx->tune.lds_pad = pad > 0 ? (size_t)pad : 0;
         if (ctx->tune.streams != 0) {

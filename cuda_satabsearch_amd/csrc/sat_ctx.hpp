@@ -50,7 +50,7 @@ struct sat_ctx {
     int32_t *d_prow = nullptr;
 
     // launch-heuristic overrides (SAT_EXP_* in satabsearch.h), read ONCE when the context is created
-    struct Tuning { int compact = -1, qlds = -1, lpc = -1, general = 0, streams = -1, upload_threads = 0, upload_timing = 0, upload_pieces = 0, epw = 0, lpc_waves = 8; size_t lds_pad = 0; } tune;
+    struct Tuning { int compact = -1, qlds = -1, lpc = -1, general = 0, streams = -1, upload_threads = 0, upload_timing = 0, upload_pieces = 0, epw = 0, lpc_waves = 0, chains = 0; size_t lds_pad = 0; } tune;
     // kernel instantiations whose dynamic-LDS limit has been raised on this device
     std::unordered_set<const void *> lds_attr_done;
     // entries per workgroup chosen for (instantiation, threads per entry, LDS bytes per entry): asked once

@@ -6,6 +6,7 @@
  *
  *   SAT_EXP_LPC = 0|1|2          log2 lanes per restart chain (default: by LDS occupancy, sat_capi.hip)
  *   SAT_EXP_LPC_WAVES = n        resident waves per CU at which that choice stops adding lanes (default 8; 12 for queries above 64 SSEs)
+ *   SAT_EXP_CHAINS = 64|128|192 restart chains per workgroup (default: one per restart, at most 256)
  *   SAT_EXP_COMPACT = 0|1        wave-level work compaction of the SA step (default: exactly when LORDER)
  *   SAT_EXP_QLDS = 0|1           query cells staged in LDS (default: queries of up to 16 SSEs)
  *   SAT_EXP_LDS_PAD = bytes      unused LDS added per db entry (occupancy experiments)

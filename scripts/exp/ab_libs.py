@@ -47,6 +47,12 @@ def workload(name):
         db, q = workloads.mixed_db(100_000), sat.synth.make_query(32)
     elif name == "c4":
         db, q, lsoln = workloads.config4_db(100_000), workloads.config4_query()[1:], True
+    elif name == "c2q101":        # the 101-SSE query of configs[2] at its restart count, on a tenth of its database
+        db, q, r = workloads.config2_db(10_000), workloads.config4_query()[1:], 4096
+    elif name == "c2q19":
+        db, q, r = workloads.config2_db(10_000), workloads.config2_queries()[0][1:], 4096
+    elif name == "c2q8":
+        db, q, r = workloads.config2_db(10_000), workloads.config2_queries()[1][1:], 4096
     elif name == "q16":
         db, q = sat.synth.make_db(100_000, 8, 32), sat.synth.make_query(12)
     else:
