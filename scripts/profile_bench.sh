@@ -8,9 +8,9 @@ repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-upload-probe"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-upload-probe --no-regimes"
 # (the trace run takes 30 timed steps, so that the first launch of the process does not weigh on the average)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 $repo/bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-upload-probe > "$out/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 $repo/bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-upload-probe --no-regimes > "$out/trace.log" 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD \
   --output-format csv -d "$out/pmc1" -- python3 $repo/bench.py $ARGS > "$out/pmc1.log" 2>&1
