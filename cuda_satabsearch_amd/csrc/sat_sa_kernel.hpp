@@ -717,8 +717,19 @@ sat_sa_kernel(const SatKernelArgs a)
         };
         if constexpr (CELLS == SAT_CELLS_TRI5) {
             // the triangle as it lies in HBM, then the null row: n2 + 1 cells that never pass the distance test
+            // (four cells per lane and trip: the entry's first cell sits at any cell index, so the 16 bytes of
+            // distances are only dword aligned and the 4 code bytes not at all - global memory takes both; their
+            // LDS images start 16-byte aligned)
             const int ncell = (n2 * n2p) >> 1;
-            for (int t = lane_id; t < ncell; t += nthreads) put(t, clean(dd[t]), tt[t]);
+            typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+            typedef uint32_t u32u_t __attribute__((aligned(1)));
+            for (int t = lane_id << 2; t + 3 < ncell; t += nthreads << 2) {
+                const f32x4u_t v = *reinterpret_cast<const f32x4u_t *>(dd + t);
+                const uint32_t c4 = *reinterpret_cast<const u32u_t *>(tt + t);
+                *reinterpret_cast<uint4 *>(distL + t) = uint4{ clean(v.x), clean(v.y), clean(v.z), clean(v.w) };
+                *reinterpret_cast<uint32_t *>(codeL + t) = c4;
+            }
+            for (int t = (ncell & ~3) + lane_id; t < ncell; t += nthreads) put(t, clean(dd[t]), tt[t]);
             for (int x = lane_id; x <= n2; x += nthreads) put(ncell + x, __float_as_uint(SAT_K_DSENT), 0u);
         } else {
             const int swave = lane_id >> 6, swaves = nthreads >> 6;
