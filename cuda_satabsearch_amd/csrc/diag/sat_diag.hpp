@@ -11,15 +11,15 @@
 //   -DSAT_DIAG_SELFCHECK    the reference's TESTING assertion (K.cu:1105-1134: score + delta == tmscord(...) on every
 //                           move): after every proposal the full score of the PROPOSED map is recomputed from scratch
 //                           and compared with score + delta; mismatches are counted in diag[8] (tests/test_gpu_parity.py)
-// Counters: SatKernelArgs::diag points at 16 u64 - [0..7] phase wave-cycles, [8] self-check mismatches, [9] checks.
+// Counters: SatKernelArgs::diag points at 16 u64 - [0..7] and [10] phase wave-cycles, [8] self-check mismatches, [9] checks.
 #pragma once
 
 #define SAT_DIAG_ARGS unsigned long long *diag;
 
 #ifdef SAT_DIAG_PHASE
-#define SAT_PHASE_INIT unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t0 = __builtin_amdgcn_s_memtime()
+#define SAT_PHASE_INIT unsigned long long ph_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t0 = __builtin_amdgcn_s_memtime()
 #define SAT_PHASE(k) do { const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime(); ph_acc[k] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
-#define SAT_PHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(a.diag + k, ph_acc[k]); } while (0)
+#define SAT_PHASE_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k = 0; k < 11; k++) if (k < 8 || k == 10) atomicAdd(a.diag + k, ph_acc[k]); } while (0)
 #endif
 
 #ifdef SAT_DIAG_FS_ROWS
@@ -111,11 +111,12 @@ inline hipError_t end(hipStream_t stream)
     e = hipMemcpy(last(), buffer(), sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost);
 #ifdef SAT_DIAG_PHASE
     unsigned long long tot = 0;
-    for (int k = 0; k < 8; k++) tot += last()[k];
-    static const char *nm[8] = { "draw+proposal", "compaction set-up", "compacted rounds", "read-back/static loops",
-                                 "best tracking", "metropolis+update", "thinit+full score", "restart loop" };
-    for (int k = 0; k < 8; k++)
-        fprintf(stderr, "phase %-24s %14llu wave-cycles %5.1f%%\n", nm[k], last()[k], tot ? 100.0 * last()[k] / tot : 0.0);
+    for (int k = 0; k < 11; k++) if (k < 8 || k == 10) tot += last()[k];
+    static const char *nm[11] = { "draw+proposal", "compaction set-up", "compacted rounds", "read-back/static loops",
+                                 "best tracking", "metropolis+update", "initial full score", "staging+restart loop", "", "",
+                                 "thinit" };
+    for (int k = 0; k < 11; k++)
+        if (k < 8 || k == 10) fprintf(stderr, "phase %-24s %14llu wave-cycles %5.1f%%\n", nm[k], last()[k], tot ? 100.0 * last()[k] / tot : 0.0);
 #endif
     return e;
 }

@@ -891,6 +891,7 @@ sat_sa_kernel(const SatKernelArgs a)
             }
         }
 
+        SAT_PHASE(10);                    // thinit
         // ---- full score of the initial map (tmscord, K.cu:396-440): pairs i < k, both matched
         int score = 0;
         constexpr bool FS_PAIRS = N1P > 16 && !SAT_DIAG_FS_ROWS_ONLY;
@@ -991,7 +992,7 @@ sat_sa_kernel(const SatKernelArgs a)
         }
 
         // ---- 100 Metropolis steps, temperature 10 * 0.95^iter (K.cu:1030-1191)
-        SAT_PHASE(6);                     // thinit + full score
+        SAT_PHASE(6);                     // full score of the initial map
         uint4 blk = uint4{ 0u, 0u, 0u, 0u };
         for (int iter = 0; iter < SAT_K_MAXITER; iter++) {
             // this step's row of the Metropolis table.  The directory is read-only for the kernel's

@@ -30,7 +30,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* diagnostic builds only: counters of the last search - [0..7] wave-cycles per SA-step phase, [8] self-check
+/* diagnostic builds only: counters of the last search - [0..7] and [10] wave-cycles per phase of the kernel, [8] self-check
  * mismatches, [9] self-checks made */
 void sat_diag_counters(unsigned long long out[16]);
 #ifdef __cplusplus
