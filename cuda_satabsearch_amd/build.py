@@ -128,11 +128,26 @@ def build_oracle(ref=False):
 
 def build_all(force=False, oracle=False, ref=False):
     build_host(force)
-    build_device(force)
-    build_cli(force)
     if oracle:
+        # the device library and its diagnostic twin (tests/native/libsat_selfcheck.so: the same sources with the
+        # reference's per-move assertion compiled in) take ~80 s of hipcc each: side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as ex:
+            dev = ex.submit(build_device, force)
+            host_objs = [os.path.join(PKG, "sat_gumbel.o"), os.path.join(PKG, "sat_shard.o")]
+            # (the twin links the same host objects: make sure they exist before both compiles start)
+            for c, o in zip([os.path.join(HOST, "sat_gumbel.c"), os.path.join(HOST, "sat_shard.c")], host_objs):
+                if force or _stale(o, [c]):
+                    dev.result()
+                    break
+            nat = ex.submit(build_test_native, force)
+            dev.result()
+            nat.result()
+        build_cli(force)
         build_oracle(ref)
-        build_test_native(force)
+    else:
+        build_device(force)
+        build_cli(force)
 
 
 if __name__ == "__main__":
