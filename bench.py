@@ -180,6 +180,17 @@ def free_port():
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks as children.  This
     process has not imported torch and never touches the GPU - no exec of a process that has."""
+    if not args.all_ranks_on_device0:
+        # (counting devices does not initialise the GPU; everything else about it is left to the ranks)
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception:
+            have = None
+        if have is not None and 0 < have < args.gpus:
+            print("bench.py: --gpus %d but only %d HIP device(s) visible (rehearse the N > 1 flow on fewer GPUs with "
+                  "--backend gloo --all-ranks-on-device0)" % (args.gpus, have), file=sys.stderr)
+            sys.exit(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
