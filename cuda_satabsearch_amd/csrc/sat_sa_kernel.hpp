@@ -144,6 +144,10 @@
 #ifndef SAT_FAST_WAVES
 #define SAT_FAST_WAVES 6
 #endif
+// the initial full score of two chains walked by a pair of lanes together (one-word sets, one lane per chain)
+#ifndef SAT_FS_TEAMS
+#define SAT_FS_TEAMS 1
+#endif
 #define SAT_K_MAXITER 100
 #define SAT_FS_UNROLL 2               // pairs per lane and round of the full score of an initial map
 #define SAT_K_STEP_BLOCK0 32          // Philox block of SA step 0 (oracle/sa_oracle.h)
@@ -934,6 +938,80 @@ sat_sa_kernel(const SatKernelArgs a)
                 bits_drop_lowest<W>(b);
                 return pos;
             };
+            // One-word sets on both sides, one lane per chain, full wave: the two lanes of a PAIR walk their two chains
+            // together.  A walk costs the wave what its busiest lane costs, and the busiest chain of 64 has ~13
+            // matched SSEs (78 pairs) where the mean has 7.7 (26): the rows of the pair's two chains (row a of a chain
+            // with m matched SSEs = its a-th matched SSE against the m - 1 - a above it) are merged in order of
+            // decreasing length and dealt to the two lanes alternately, so both lanes of the pair meet rows of nearly
+            // equal length in the same trip and each does half of the pair's work.  A lane needs its partner's two
+            // sets (two shuffles) and hands the partner's share of the sums back at the end (one more).  Bench shape
+            // 10.85 -> 10.71 ms (+1.3 %): the walk's ~2300 VALU instructions per restart become ~1800 - the kernel is
+            // issue bound, so that, not the shorter dependent chain of loads, is what the gain is.
+            // (not with LSOLN: four more live registers there end up in scratch)
+            constexpr bool FS_TEAMS = SAT_FS_TEAMS && M1W == 1 && M2W == 1 && FAST && (OPT == 0 || OPT == 1);
+            bool teamed = false;
+            if constexpr (FS_TEAMS) teamed = __builtin_amdgcn_ballot_w64(true) == ~0ull;
+            if (FS_TEAMS && teamed) {
+                const int pl = wlane & 1;
+                const uint32_t om = (uint32_t)__shfl_xor((int)mapped.w[0], 1, 64), oo = (uint32_t)__shfl_xor((int)occ.w[0], 1, 64);
+                const uint32_t m0 = pl ? om : mapped.w[0], o0 = pl ? oo : occ.w[0];       // chain 0: the even lane's
+                const uint32_t m1 = pl ? mapped.w[0] : om, o1 = pl ? occ.w[0] : oo;
+                const int c0n = __popc(m0), c1n = __popc(m1);
+                const bool big1 = c1n > c0n;                                             // the longer chain leads the merged order
+                const uint32_t mb = big1 ? m1 : m0, ob = big1 ? o1 : o0, msm = big1 ? m0 : m1, osm = big1 ? o0 : o1;
+                const int rb = max((big1 ? c1n : c0n) - 1, 0), rs = max((big1 ? c0n : c1n) - 1, 0);   // rows with partners
+                const int dlead = rb - rs, etot = rb + rs;
+                uint32_t rm = mb, ro = ob;                 // the stream this lane is on: its sets with the rows below `cur` stripped
+                int cur = 0, acc_b = 0, acc_s = 0;
+                bool on_small = false;
+                // element e of the merged order: the first dlead are rows 0 .. of the longer chain (lengths rb .. rs + 1),
+                // then lengths rs .. 1 twice each, longer chain first.  This lane takes e = pl, pl + 2, ...: the leading
+                // rows of the longer chain two apart, then ONE of the two chains row after row (e - dlead keeps its parity).
+                for (int e = pl; __builtin_amdgcn_ballot_w64(e < etot) != 0ull; e += 2) {
+                    const bool act = e < etot;
+                    const int e2 = e - dlead;
+                    const bool small = e2 >= 0 && (e2 & 1) != 0;
+                    const int len = e2 < 0 ? rb - e : rs - (e2 >> 1);
+                    const int a = (small ? rs : rb) - len;
+                    if (small && !on_small) { rm = msm; ro = osm; cur = 0; on_small = true; }
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {                           // at most two rows further on
+                        const uint32_t go = (act && cur < a) ? 1u : 0u;
+                        rm &= rm - go;
+                        ro &= ro - go;
+                        cur += (int)go;
+                    }
+                    const int i = act ? __ffs(rm) - 1 : 0, ji = act ? __ffs(ro) - 1 : 0;
+                    Bits<1> rk, rl;
+                    rk.w[0] = act ? rm & (rm - 1u) : 0u;
+                    rl.w[0] = act ? ro & (ro - 1u) : 0u;
+                    const DbRow<CELLS> drow = db_row(ji);
+                    const uint32_t qrow = (uint32_t)__mul24(i, N1P * 8);
+                    int rowsum = 0;
+                    while (__builtin_amdgcn_ballot_w64(rk.w[0] != 0u) != 0ull) {
+                        int ll[SAT_FS_UNROLL];
+                        bool vv[SAT_FS_UNROLL];
+                        u32x2_t qcell[SAT_FS_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < SAT_FS_UNROLL; u++) {
+                            bool vl;
+                            const int k = pop(rk, vv[u]);
+                            ll[u] = pop(rl, vl);
+                            qcell[u] = *(gptr_u2)(qpairG + (qrow + ((uint32_t)k << 3)));
+                        }
+#pragma unroll
+                        for (int u = 0; u < SAT_FS_UNROLL; u++) {
+                            const uint2 c = db_cell<CELLS>(drow, ll[u]);
+                            const int term = pair_term(qcell[u].x, qcell[u].y, c.x, c.y);
+                            rowsum += vv[u] ? term : 0;
+                        }
+                    }
+                    acc_s += small ? rowsum : 0;
+                    acc_b += small ? 0 : rowsum;
+                }
+                const int acc0 = big1 ? acc_s : acc_b, acc1 = big1 ? acc_b : acc_s;          // by chain
+                score = (pl ? acc1 : acc0) + __shfl_xor(pl ? acc0 : acc1, 1, 64);
+            } else
             while (__builtin_amdgcn_ballot_w64(bits_any<M1W>(ri)) != 0ull) {
                 bool ai, aj;
                 const int i = pop(ri, ai);
