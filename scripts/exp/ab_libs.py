@@ -41,6 +41,10 @@ def workload(name):
         db, q = sat.synth.make_db(60_000, 8, 32), workloads.config4_query()[1:]
     elif name == "n96":
         db, q = sat.synth.make_db(20_000, 96, 96), sat.synth.make_query(32)
+    elif name == "n40":
+        db, q = sat.synth.make_db(60_000, 40, 40), sat.synth.make_query(32)
+    elif name == "n48":
+        db, q = sat.synth.make_db(50_000, 48, 48), sat.synth.make_query(32)
     elif name == "n64":
         db, q = sat.synth.make_db(40_000, 64, 64), sat.synth.make_query(32)
     elif name == "mixed":
@@ -53,6 +57,8 @@ def workload(name):
         db, q, r = workloads.config2_db(10_000), workloads.config2_queries()[0][1:], 4096
     elif name == "c2q8":
         db, q, r = workloads.config2_db(10_000), workloads.config2_queries()[1][1:], 4096
+    elif name.startswith("qn"):       # qnNN: a synthetic NN-SSE query x 60 000 sorted entries of 4..40 SSEs (the query list's database shape)
+        db, q = sat.synth.make_db(60_000, 4, 40, sort=True), sat.synth.make_query(int(name[2:]))
     elif name == "q16":
         db, q = sat.synth.make_db(100_000, 8, 32), sat.synth.make_query(12)
     else:
