@@ -154,11 +154,13 @@ int gather_to_device0(sat_multi *m, T *dst, size_t count, ncclDataType_t type, S
         ncclResult_t r = g_rccl.GroupStart();
         bool ok = r == ncclSuccess;
         for (int g = 0; ok && g < m->ndev; g++) {
-            HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+            if (hipSetDevice(m->devices[(size_t)g]) != hipSuccess) {       // (never leave the group open)
+                (void)g_rccl.GroupEnd();
+                return sat_fail(SAT_EDEVICE, "hipSetDevice(%d) failed inside the gather", m->devices[(size_t)g]);
+            }
             r = g_rccl.Gather(src(g), dst, count, type, 0, m->comm[(size_t)g], m->ctx[(size_t)g]->stream);
             ok = r == ncclSuccess;
         }
-        if (r != ncclSuccess && ok) ok = false;
         const ncclResult_t rend = g_rccl.GroupEnd();
         if (ok && rend == ncclSuccess) return SAT_OK;
         // RCCL refused the gather at run time: unless the caller insisted on it, take the peer-copy path from
