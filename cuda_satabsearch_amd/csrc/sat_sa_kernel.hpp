@@ -321,6 +321,29 @@ template <int W> __device__ __forceinline__ int bits_select(const Bits<W> &b, in
     return found ? base + word_select(word, rr) : 0;
 }
 
+// p = the highest set bit of `mapped` at or below position `upto` (0 when there is none: `none`).  One and two
+// words as 32- and 64-bit arithmetic, more words word by word.
+template <int W> __device__ __forceinline__ void highest_mapped_upto(const Bits<W> &mapped, int upto, int &p, bool &none)
+{
+    if constexpr (W == 1) {
+        const uint32_t low = mapped.w[0] & (0xFFFFFFFFu >> (31 - upto));
+        p = 31 ^ __builtin_clz(low | 1u);
+        none = low == 0u;
+    } else if constexpr (W == 2) {
+        const unsigned long long m = (unsigned long long)mapped.w[0] | ((unsigned long long)mapped.w[1] << 32);
+        const unsigned long long low = m & (~0ull >> (63 - upto));
+        p = 63 ^ __builtin_clzll(low | 1ull);
+        none = low == 0ull;
+    } else {
+        Bits<W> lowpart, below = bits_below<W>(upto + 1);
+#pragma unroll
+        for (int w = 0; w < W; w++) lowpart.w[w] = mapped.w[w] & below.w[w];
+        p = bits_highest<W>(lowpart);
+        none = p < 0;
+        p = none ? 0 : p;
+    }
+}
+
 // ---------------------------------------------------------------- pair scores
 // Sum of the four pair scores of one map word: query SSEs 4kw..4kw+3 against the db SSEs
 // in `word` (one byte each), all on db row `row` (the image of the moved / anchor SSE).
@@ -1113,21 +1136,9 @@ sat_sa_kernel(const SatKernelArgs a)
                 // image, the window [startj, endj) of K.cu:1053-1077 is the run of free bits
                 // between A and the next occupied bit above it: no second and third map read, no
                 // range masks.  p == ssei exactly when ssei is mapped, so A is also its old image.
-                Bits<M1W> lowpart;
                 int p;
                 bool none;
-                if constexpr (M1W == 1) {
-                    lowpart.w[0] = mapped.w[0] & (0xFFFFFFFFu >> (31 - ssei));
-                    p = 31 ^ __builtin_clz(lowpart.w[0] | 1u);
-                    none = lowpart.w[0] == 0u;
-                } else {
-                    Bits<M1W> upto = bits_below<M1W>(ssei + 1);
-#pragma unroll
-                    for (int w = 0; w < M1W; w++) lowpart.w[w] = mapped.w[w] & upto.w[w];
-                    p = bits_highest<M1W>(lowpart);
-                    none = p < 0;
-                    p = none ? 0 : p;
-                }
+                highest_mapped_upto(mapped, ssei, p, none);
                 const int A = smap_b[map_byte_addr(p)];
                 SAT_DIAG_DUP_MAPBYTE(&smap_b[map_byte_addr(p)]);
                 oldj = p == ssei ? A : NULLJ;
@@ -1138,6 +1149,26 @@ sat_sa_kernel(const SatKernelArgs a)
                 // successor: endj = -1, empty, unless ssei is the last query SSE (K.cu:1064-1077)
                 const bool empty = none || (y == 0u && ssei != n1 - 1);
                 cand.w[0] = empty ? 0u : (qmask[ssei] & gap);
+            } else if (M2W == 2 && FAST && opt_lorder) {
+                // The same for entries of 33..64 SSEs with the two words of the db-side sets taken as ONE 64-bit
+                // word: p, A and the old image as above, the window is the run of free bits between A and the next
+                // occupied bit - (y - 1) & ~y on 64 bits - where the general path below reads three map bytes (two of
+                // them behind the first) and builds four range masks word by word.
+                int p;
+                bool none;
+                highest_mapped_upto(mapped, ssei, p, none);
+                const int t = qtypes[ssei];
+                const int A = smap_b[map_byte_addr(p)];
+                oldj = p == ssei ? A : NULLJ;
+                const unsigned long long occ64 = (unsigned long long)occ.w[0] | ((unsigned long long)occ.w[1] << 32);
+                const unsigned long long above = (~1ull) << (A & 63);             // bits A+1 .. 63 (A = 64: no mapped SSE, `empty`)
+                const unsigned long long y = occ64 & above;                       // occupied above A
+                const unsigned long long gap = (y - 1ull) & ~y & above;           // free run up to the next occupied bit
+                const unsigned long long tm = *reinterpret_cast<const unsigned long long *>(&tmask[t * TMS]);
+                const bool empty = none || (y == 0ull && ssei != n1 - 1);
+                const unsigned long long c64 = empty ? 0ull : (tm & gap);
+                cand.w[0] = (uint32_t)c64;
+                cand.w[M2W - 1] = (uint32_t)(c64 >> 32);
             } else {
                 oldj = smap_b[map_byte_addr(ssei)];
                 int startj = 0, endj = n2;
@@ -1185,6 +1216,20 @@ sat_sa_kernel(const SatKernelArgs a)
                     left -= (int)go;
                 }
                 sel = __ffs(c) - 1;
+            } else if (M2W == 2 && FAST && opt_lorder) {
+                unsigned long long c = (unsigned long long)cand.w[0] | ((unsigned long long)cand.w[M2W - 1] << 32);
+                int left = pick;
+                {
+                    const unsigned long long go = left > 0 ? 1ull : 0ull;
+                    c &= c - go;
+                    left -= (int)go;
+                }
+                while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
+                    const unsigned long long go = left > 0 ? 1ull : 0ull;
+                    c &= c - go;
+                    left -= (int)go;
+                }
+                sel = __ffsll((long long)c) - 1;
             } else {
                 sel = bits_select<M2W>(cand, pick);
             }
