@@ -1169,6 +1169,30 @@ sat_sa_kernel(const SatKernelArgs a)
                 const unsigned long long c64 = empty ? 0ull : (tm & gap);
                 cand.w[0] = (uint32_t)c64;
                 cand.w[M2W - 1] = (uint32_t)(c64 >> 32);
+            } else if (M2W == 4 && FAST && opt_lorder) {
+                // ... and for entries above 64 SSEs as two 64-bit halves: y - 1 borrows from the upper half exactly
+                // when no bit of the lower half is occupied above A.
+                int p;
+                bool none;
+                highest_mapped_upto(mapped, ssei, p, none);
+                const int t = qtypes[ssei];
+                const int A = smap_b[map_byte_addr(p)];
+                oldj = p == ssei ? A : NULLJ;
+                const unsigned long long occ_lo = (unsigned long long)occ.w[0] | ((unsigned long long)occ.w[1] << 32),
+                                         occ_hi = (unsigned long long)occ.w[2] | ((unsigned long long)occ.w[3] << 32);
+                const unsigned long long base = (~1ull) << (A & 63);               // (A & 63 = 63: nothing above it in its half)
+                const bool a_hi = A >= 64;
+                const unsigned long long above_lo = a_hi ? 0ull : base, above_hi = a_hi ? base : ~0ull;
+                const unsigned long long y_lo = occ_lo & above_lo, y_hi = occ_hi & above_hi;      // occupied above A
+                const unsigned long long gap_lo = (y_lo - 1ull) & ~y_lo & above_lo;
+                const unsigned long long gap_hi = (y_hi - (y_lo == 0ull ? 1ull : 0ull)) & ~y_hi & above_hi;
+                const unsigned long long *tm = reinterpret_cast<const unsigned long long *>(&tmask[t * TMS]);
+                const bool empty = none || ((y_lo | y_hi) == 0ull && ssei != n1 - 1);
+                const unsigned long long c_lo = empty ? 0ull : (tm[0] & gap_lo), c_hi = empty ? 0ull : (tm[1] & gap_hi);
+                cand.w[0] = (uint32_t)c_lo;
+                cand.w[1 % M2W] = (uint32_t)(c_lo >> 32);
+                cand.w[2 % M2W] = (uint32_t)c_hi;
+                cand.w[3 % M2W] = (uint32_t)(c_hi >> 32);
             } else {
                 oldj = smap_b[map_byte_addr(ssei)];
                 int startj = 0, endj = n2;
@@ -1216,20 +1240,31 @@ sat_sa_kernel(const SatKernelArgs a)
                     left -= (int)go;
                 }
                 sel = __ffs(c) - 1;
-            } else if (M2W == 2 && FAST && opt_lorder) {
+            } else if (M2W == 2 && FAST && opt_lorder && __builtin_amdgcn_ballot_w64(pick > 2) == 0ull) {
+                // (wide windows - a short query against a long entry - hold many candidates: the strip loop runs as
+                // often as the largest pick of the wave, so it is taken only while every pick is small; else the rank select)
                 unsigned long long c = (unsigned long long)cand.w[0] | ((unsigned long long)cand.w[M2W - 1] << 32);
                 int left = pick;
-                {
-                    const unsigned long long go = left > 0 ? 1ull : 0ull;
-                    c &= c - go;
-                    left -= (int)go;
-                }
-                while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
                     const unsigned long long go = left > 0 ? 1ull : 0ull;
                     c &= c - go;
                     left -= (int)go;
                 }
                 sel = __ffsll((long long)c) - 1;
+            } else if (M2W == 4 && FAST && opt_lorder && __builtin_amdgcn_ballot_w64(pick > 2) == 0ull) {
+                unsigned long long c_lo = (unsigned long long)cand.w[0] | ((unsigned long long)cand.w[1 % M2W] << 32),
+                                   c_hi = (unsigned long long)cand.w[2 % M2W] | ((unsigned long long)cand.w[3 % M2W] << 32);
+                int left = pick;
+                // strips the lowest candidate: of the lower half while it has one, else of the upper half
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const bool go = left > 0, in_lo = c_lo != 0ull;
+                    c_lo &= c_lo - ((go && in_lo) ? 1ull : 0ull);
+                    c_hi &= c_hi - ((go && !in_lo) ? 1ull : 0ull);
+                    left -= go ? 1 : 0;
+                }
+                sel = c_lo != 0ull ? __ffsll((long long)c_lo) - 1 : 63 + __ffsll((long long)c_hi);
             } else {
                 sel = bits_select<M2W>(cand, pick);
             }
