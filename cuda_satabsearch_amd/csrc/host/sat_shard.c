@@ -3,15 +3,15 @@
 #include "sat_shard.h"
 
 /* ns per scoring, 32-SSE query, r = 128, one MI355X (scripts/cost_sweep.py in round 3, after the triangle cell
- * layout for entries above 48 SSEs: profiles/r03_cost_by_order.txt; an entry of 111 SSEs costs 4.4 entries of 32,
- * where the full cell matrix made it 5.4) */
+ * layout for entries above 48 SSEs: profiles/r03_cost_by_order.txt; an entry of 111 SSEs costs 4.2 entries of 32,
+ * where the full cell matrix made it 5.4; re-measured after the 64-bit order windows) */
 static const struct { int order; double ns; } k_cost[] = {
-    { 4, 46.9 }, { 8, 55.1 }, { 12, 62.6 }, { 16, 69.2 }, { 20, 75.9 }, { 24, 80.3 }, { 28, 85.7 }, { 32, 88.9 },
-    { 40, 123.3 }, { 48, 152.1 }, { 56, 181.2 }, { 64, 194.4 }, { 72, 247.0 }, { 80, 271.2 }, { 88, 307.9 }, { 96, 332.7 },
-    { 104, 387.8 }, { 111, 394.0 },
+    { 4, 47.8 }, { 8, 55.4 }, { 12, 63.6 }, { 16, 71.8 }, { 20, 77.5 }, { 24, 81.6 }, { 28, 86.6 }, { 32, 91.6 },
+    { 40, 120.1 }, { 48, 146.6 }, { 56, 175.0 }, { 64, 191.6 }, { 72, 241.2 }, { 80, 264.0 }, { 88, 292.1 }, { 96, 321.6 },
+    { 104, 370.1 }, { 111, 383.2 },
 };
 #define K_COST_N ((int)(sizeof(k_cost) / sizeof(k_cost[0])))
-#define K_COST_UNIT 88.9
+#define K_COST_UNIT 91.6
 
 double sat_entry_cost(int order)
 {
