@@ -59,6 +59,12 @@ def workload(name):
         db, q, r = workloads.config2_db(10_000), workloads.config2_queries()[1][1:], 4096
     elif name.startswith("qn"):       # qnNN: a synthetic NN-SSE query x 60 000 sorted entries of 4..40 SSEs (the query list's database shape)
         db, q = sat.synth.make_db(60_000, 4, 40, sort=True), sat.synth.make_query(int(name[2:]))
+    elif name.startswith("real"):     # realNN: an NN-SSE query x 200 000 sorted entries of 3..32 SSEs with the reference database's skew
+        import numpy as np
+        rng = np.random.default_rng(11)
+        # the example database: 71 % of the entries up to 16 SSEs, 24 % 17..32, median 11 (tests/golden/inputs)
+        orders = np.sort(np.clip(np.round(rng.gamma(2.6, 5.2, size=200_000)).astype(np.int32), 3, 32))
+        db, q = sat.synth.make_db(200_000, orders=orders), sat.synth.make_query(int(name[4:]))
     elif name == "q16":
         db, q = sat.synth.make_db(100_000, 8, 32), sat.synth.make_query(12)
     else:
