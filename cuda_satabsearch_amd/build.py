@@ -57,18 +57,24 @@ def build_host(force=False):
     return out
 
 
+def _host_objects(force=False):
+    """plain-C host pieces linked into the device library (and its diagnostic twin): the Gumbel statistics (the
+    context tabulates them with the host libm for the device-side best-k rows) and the shard cost model"""
+    host_c = [os.path.join(HOST, "sat_gumbel.c"), os.path.join(HOST, "sat_shard.c")]
+    host_o = [os.path.join(PKG, "sat_gumbel.o"), os.path.join(PKG, "sat_shard.o")]
+    for c, o in zip(host_c, host_o):
+        if force or _stale(o, [c, os.path.join(HOST, "sat_gumbel.h"), os.path.join(HOST, "sat_shard.h")]):
+            _run([CC, "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-I", HOST, "-c", "-o", o, c])
+    return host_o
+
+
 def build_device(force=False):
     out = os.path.join(PKG, "libsatabsearch.so")
     srcs = [os.path.join(CSRC, "sat_capi.hip"), os.path.join(CSRC, "sat_topk.hip"), os.path.join(CSRC, "sat_multi.hip")]
-    # plain-C host pieces linked in as well: the Gumbel statistics (the context tabulates them with the
-    # host libm for the device-side best-k rows) and the shard cost model (multi-GPU cuts)
-    host_c = [os.path.join(HOST, "sat_gumbel.c"), os.path.join(HOST, "sat_shard.c")]
-    host_o = [os.path.join(PKG, "sat_gumbel.o"), os.path.join(PKG, "sat_shard.o")]
-    deps = srcs + host_c + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
-                            os.path.join(INC, "satabsearch.h"), os.path.join(HOST, "sat_gumbel.h"), os.path.join(HOST, "sat_shard.h")]
+    host_o = _host_objects(force)
+    deps = srcs + host_o + [os.path.join(CSRC, "sat_sa_kernel.hpp"), os.path.join(CSRC, "sat_ctx.hpp"),
+                            os.path.join(INC, "satabsearch.h")]
     if force or _stale(out, deps):
-        for c, o in zip(host_c, host_o):
-            _run([CC, "-O2", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-I", HOST, "-c", "-o", o, c])
         # -Wl,: hipcc would compile a bare .o as HIP source.  librccl is NOT linked: sat_multi.hip loads it on demand
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
               "-I", INC, "-I", CSRC, "-o", out] + srcs + ["-Wl," + o for o in host_o] + ["-lm", "-ldl"])
@@ -128,18 +134,13 @@ def build_oracle(ref=False):
 
 def build_all(force=False, oracle=False, ref=False):
     build_host(force)
+    _host_objects(force)
     if oracle:
         # the device library and its diagnostic twin (tests/native/libsat_selfcheck.so: the same sources with the
-        # reference's per-move assertion compiled in) take ~80 s of hipcc each: side by side
+        # reference's per-move assertion compiled in) take ~100 s of hipcc each: side by side
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(2) as ex:
-            dev = ex.submit(build_device, force)
-            host_objs = [os.path.join(PKG, "sat_gumbel.o"), os.path.join(PKG, "sat_shard.o")]
-            # (the twin links the same host objects: make sure they exist before both compiles start)
-            for c, o in zip([os.path.join(HOST, "sat_gumbel.c"), os.path.join(HOST, "sat_shard.c")], host_objs):
-                if force or _stale(o, [c]):
-                    dev.result()
-                    break
+            dev = ex.submit(build_device, False if not force else True)
             nat = ex.submit(build_test_native, force)
             dev.result()
             nat.result()
