@@ -1037,36 +1037,43 @@ sat_sa_kernel(const SatKernelArgs a)
             } else
             while (__builtin_amdgcn_ballot_w64(bits_any<M1W>(ri)) != 0ull) {
                 bool ai, aj;
-                const int i = pop(ri, ai);
-                int ji;                                                    // (a lane that is done walks row 0, sums nothing)
-                if constexpr (POP_IMAGES) ji = pop(rj, aj);
-                else { ji = smap_b[map_byte_addr(i)]; ji = ai ? ji : 0; }
+                // The lanes that share a chain take its ROWS in turn: every trip pops lpc matched SSEs, lane `part`
+                // keeps the part-th as its row - with the matched SSEs above THAT one as the row's partners - and each
+                // lane then walks its own row's partners alone.  (The first version shared every row: all lanes popped
+                // the same partner sequence and kept every lpc-th, i.e. every lane paid every pop - and the pops of a
+                // four-word set are most of a pair's instructions.)
+                int i = 0, ji = 0;                                         // (a lane that is done walks row 0, sums nothing)
+                ai = false;
+                Bits<M1W> rk = bits_zero<M1W>();                           // the matched SSEs above i ...
+                Bits<M2W> rl = bits_zero<M2W>();                           // ... and their images
+                for (int p = 0; p < lpc; p++) {
+                    bool v;
+                    const int pos = pop(ri, v);
+                    int img = 0;
+                    if constexpr (POP_IMAGES) { bool vj; img = pop(rj, vj); }
+                    if (p == part) {
+                        i = pos;
+                        ai = v;
+                        ji = img;
+                        rk = ri;
+                        rl = rj;
+                    }
+                }
+                (void)aj;
+                if constexpr (!POP_IMAGES) { ji = smap_b[map_byte_addr(i)]; ji = ai ? ji : 0; }
                 const DbRow<CELLS> drow = db_row(ji);
                 const uint32_t qrow = (uint32_t)__mul24(i, N1P * 8);
-                Bits<M1W> rk = ri;                                         // the matched SSEs above i ...
-                Bits<M2W> rl = rj;                                         // ... and their images
                 int rowsum = 0;
-                // SAT_FS_UNROLL pairs per lane and round, their loads in flight together; the lanes that share
-                // a chain take turns at the SSEs (all pop the same sequence, lane `part` keeps every lpc-th)
+                // SAT_FS_UNROLL pairs per lane and round, their loads in flight together
                 while (__builtin_amdgcn_ballot_w64(bits_any<M1W>(rk)) != 0ull) {
                     int ll[SAT_FS_UNROLL];
                     bool vv[SAT_FS_UNROLL];
                     u32x2_t qcell[SAT_FS_UNROLL];
 #pragma unroll
                     for (int u = 0; u < SAT_FS_UNROLL; u++) {
-                        int ku = 0;
+                        const int ku = pop(rk, vv[u]);
                         ll[u] = 0;
-                        vv[u] = false;
-                        for (int p = 0; p < lpc; p++) {
-                            bool v, vl;
-                            const int k = pop(rk, v);
-                            ku = p == part ? k : ku;
-                            vv[u] = p == part ? v : vv[u];
-                            if constexpr (POP_IMAGES) {
-                                const int l = pop(rl, vl);
-                                ll[u] = p == part ? l : ll[u];
-                            }
-                        }
+                        if constexpr (POP_IMAGES) { bool vl; ll[u] = pop(rl, vl); }
                         // (none left: SSE 0's image, possibly the null column - it exists, and the term is dropped)
                         if constexpr (!POP_IMAGES) ll[u] = smap_b[map_byte_addr(ku)];
                         qcell[u] = *(gptr_u2)(qpairG + (qrow + ((uint32_t)ku << 3)));
