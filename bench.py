@@ -199,9 +199,12 @@ def launch_ranks(args, argv):
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     got_line = False
     for line in p.stdout:
-        sys.stdout.write(line)
-        sys.stdout.flush()
-        got_line = got_line or line.lstrip().startswith("{")
+        # stdout carries the ONE result line; whatever else the ranks' libraries print there (gloo announces its
+        # connections on stdout) goes to stderr
+        is_result = line.lstrip().startswith("{")
+        (sys.stdout if is_result else sys.stderr).write(line)
+        (sys.stdout if is_result else sys.stderr).flush()
+        got_line = got_line or is_result
     rc = p.wait()
     if rc == 0 and not got_line:
         print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
